@@ -1,0 +1,126 @@
+/*
+ * ntedit_oracle.h -- CPU restatement of ntEdit v2.1.1's k-mer Bloom-filter
+ * membership + edit-search path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is the parity oracle: a plain-C restatement of the reference algorithm
+ * (reference: ntedit.cpp; every function cites the file:line it follows).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * call into this directory.  The product (ntedit_amd/) never links it.
+ *
+ * PARITY STATUS
+ *   - control logic (screen / confirm / substitution + indel sweep / apply /
+ *     writers): soft-pinned by the reference's only fixture,
+ *     demo/ecoli_ntedit_k25_changes.tsv (see tests/test_oracle_demo.py:
+ *     >=99% of the 4,997 rows reproduced with a proxy Bloom filter).
+ *   - hashing + Bloom-filter file format: these live in btllib, which is an
+ *     un-vendored, un-pinned dependency of the reference (meson.build:20;
+ *     ntedit.cpp:24-26) and is absent from /root/reference.  The restatement
+ *     below follows the published ntHash2 / btllib algorithm from memory.
+ *     ==> hashing parity with real btllib-built filters is "PARITY UNPINNED".
+ *   - the reference cannot be compiled here (needs btllib + Boost headers the
+ *     image lacks), so there is no oracle/_ref build.
+ */
+#ifndef NTEDIT_ORACLE_H
+#define NTEDIT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- ntHash2 primitives (btllib hashing_internals; call sites ntedit.cpp:412-415,428-431,444-451) */
+uint64_t ora_srol(uint64_t x);
+uint64_t ora_srol_n(uint64_t x, unsigned d);
+uint64_t ora_sror(uint64_t x);
+uint64_t ora_seed(unsigned char c); /* SEED_TAB[c] */
+uint64_t ora_base_forward_hash(const char* s, unsigned k);
+uint64_t ora_base_reverse_hash(const char* s, unsigned k);
+uint64_t ora_next_forward_hash(uint64_t fh, unsigned k, unsigned char out, unsigned char in);
+uint64_t ora_next_reverse_hash(uint64_t rh, unsigned k, unsigned char out, unsigned char in);
+void ora_extend_hashes(uint64_t base, unsigned k, unsigned h, uint64_t* hv);
+
+/* ---- Bloom filter (btllib KmerBloomFilter / KmerCountingBloomFilter8; ntedit.cpp:350-401) */
+typedef struct
+{
+	uint8_t* data;
+	uint64_t bytes;     /* array size in bytes (multiple of 8) */
+	uint64_t bits;      /* bytes*8 (plain BF) */
+	unsigned hash_num;
+	unsigned k;
+	int counting;       /* 1 = KmerCountingBloomFilter8 */
+	int owns;
+} ora_bf;
+
+int ora_bf_init(ora_bf* bf, uint64_t bytes, unsigned hash_num, unsigned k, int counting);
+void ora_bf_free(ora_bf* bf);
+int ora_bf_load(ora_bf* bf, const char* path);
+int ora_bf_save(const ora_bf* bf, const char* path);
+/* returns membership (plain) or min count (counting) -- like btllib contains() */
+unsigned ora_bf_contains(const ora_bf* bf, const uint64_t* hv);
+void ora_bf_insert(ora_bf* bf, const uint64_t* hv);
+/* insert every k-mer made only of ACGTacgt of seq[0..len) (canonical hash) */
+void ora_bf_insert_seq(ora_bf* bf, const char* seq, size_t len);
+
+/* ---- parameters (ntedit.cpp:99-133 opt:: globals after main()'s clamping 2438-2493) */
+typedef struct
+{
+	unsigned k, h;
+	unsigned jump;
+	unsigned min_contig_len;
+	unsigned max_insertions, max_deletions;
+	float edit_threshold, missing_threshold;
+	float edit_ratio, missing_ratio;
+	int use_ratio;
+	unsigned insertion_cap;
+	int mode, snv, mask, secbf;
+	unsigned min_threshold, max_threshold;
+} ora_params;
+
+void ora_params_default(ora_params* p);
+/* applies main()'s post-load fixups (ntedit.cpp:2439-2493); returns 0 */
+int ora_params_finalize(ora_params* p, const ora_bf* bloom);
+
+/* ---- per-contig polish (ntedit.cpp:1747-2151) + writers (925-1213) */
+/* seq is modified in place exactly as the reference modifies contigSeq.
+ * fa/tsv may be NULL (then nothing is written for that stream). */
+void ora_polish_contig(
+    const char* hdr,
+    char* seq,
+    unsigned len,
+    const ora_params* p,
+    const ora_bf* bloom,
+    const ora_bf* bloomrep,
+    FILE* fa,
+    FILE* tsv);
+
+void ora_write_tsv_header(FILE* tsv, const ora_params* p, const ora_bf* bloom);
+
+/* whole-file driver = readAndCorrect at -t 1 (ntedit.cpp:2154-2259) */
+int ora_polish_file(
+    const char* draft_path,
+    const ora_params* p,
+    const ora_bf* bloom,
+    const ora_bf* bloomrep,
+    const char* prefix,
+    uint64_t* bases_out);
+
+/* ---- step-1 screen only: absent bit for every k-mer start the reference's
+ * main loop would test in an un-edited contig (ntedit.cpp:1798-1807,2119-2138).
+ * bitmap has ceil(len/64) words; bit i set <=> k-mer [i,i+k) is all accepted
+ * bases and NOT in the filter. */
+void ora_screen(const char* seq, size_t len, const ora_bf* bloom, uint64_t* bitmap);
+
+/* counters for work-profile checks */
+typedef struct
+{
+	uint64_t rolls, contains, bitreads;
+} ora_counters;
+extern ora_counters ora_ctr;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

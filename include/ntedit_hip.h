@@ -1,0 +1,188 @@
+/*
+ * ntedit_hip.h -- C ABI of the MI355X-native ntEdit hot path.
+ *
+ * The reference has no plugin/FFI seam; its hot path is one C++ call,
+ *     kmerizeAndCorrect(hdr, seq, len, bloom, bloomrep, dfout, rfout, vfout, clinvar)
+ * (ntedit.cpp:1747-1757) made per contig from readAndCorrect's OpenMP loop
+ * (ntedit.cpp:2242-2245), with its parameters in the opt:: globals
+ * (ntedit.cpp:99-133).  This header is the boundary a maintainer would bind
+ * in its place: plain C, plain pointers and sizes, no C++/torch types.
+ * INTEGRATION.md shows the reference-side stub.
+ *
+ * All functions return 0 on success or a negative NTEDIT_E_* code;
+ * ntedit_hip_last_error() gives a message.  The host maps a failure to the
+ * reference's convention (`ntEdit: error: ...` on stderr, exit(EXIT_FAILURE),
+ * ntedit.cpp:476-483,2442-2445).  Nothing here falls back to the CPU: without
+ * a HIP device every compute entry point fails with NTEDIT_E_DEVICE.
+ */
+#ifndef NTEDIT_HIP_H
+#define NTEDIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTEDIT_OK 0
+#define NTEDIT_E_ARG (-1)      /* bad argument / unsupported option        */
+#define NTEDIT_E_DEVICE (-2)   /* HIP runtime error or no device           */
+#define NTEDIT_E_NOFILTER (-3) /* primary Bloom filter not set             */
+#define NTEDIT_E_OVERFLOW (-4) /* internal capacity exceeded after retries */
+#define NTEDIT_E_IO (-5)       /* file could not be read / written         */
+#define NTEDIT_E_UNSUPPORTED (-6) /* counting BF / SNV mode: not on this path yet */
+
+#define NTEDIT_FILTER_PRIMARY 0   /* -r  (ntedit.cpp:2438) */
+#define NTEDIT_FILTER_SECONDARY 1 /* -e  (ntedit.cpp:2570) */
+
+typedef struct ntedit_hip_ctx ntedit_hip_ctx;
+typedef struct ntedit_hip_result ntedit_hip_result;
+
+/* The opt:: parameter block (ntedit.cpp:99-133).  k and h are taken from the
+ * primary filter (ntedit.cpp:2439,2448), not from -k. */
+typedef struct ntedit_hip_params
+{
+	uint32_t min_contig_len;   /* -z (host-side drop, ntedit.cpp:2242) */
+	uint32_t max_insertions;   /* -i */
+	uint32_t max_deletions;    /* -d */
+	float edit_threshold;      /* -y */
+	float missing_threshold;   /* -x */
+	float edit_ratio;          /* -Y */
+	float missing_ratio;       /* -X */
+	int32_t use_ratio;         /* set when -X or -Y was given */
+	uint32_t jump;             /* -j */
+	int32_t mode;              /* -m */
+	int32_t snv;               /* -s (unsupported on this path: NTEDIT_E_UNSUPPORTED) */
+	int32_t mask;              /* -a */
+	uint32_t min_threshold;    /* -p (counting filters only) */
+	uint32_t max_threshold;    /* -q (counting filters only) */
+	/* tuning, not part of the reference surface (0 = default) */
+	uint32_t start_grid;       /* extra event start every N positions in an absent run (power of 2) */
+	uint32_t node_window;      /* rope nodes kept live per event thread */
+} ntedit_hip_params;
+
+/* defaults of ntedit.cpp:99-133 */
+void ntedit_hip_params_default(ntedit_hip_params* p);
+/* main()'s clamping after the filter is known (ntedit.cpp:2411-2413,2478-2493).
+ * warn (may be NULL, cap bytes) receives the reference's warning texts. */
+void ntedit_hip_params_clamp(ntedit_hip_params* p, char* warn, size_t cap);
+
+int ntedit_hip_create(int device, ntedit_hip_ctx** out);
+void ntedit_hip_destroy(ntedit_hip_ctx* ctx);
+const char* ntedit_hip_last_error(const ntedit_hip_ctx* ctx);
+
+/* ---- Bloom filters (replaces BFWrapper, ntedit.cpp:350-401) -------------
+ * bits: the btllib bit array (LSB-first within a byte), nbytes a multiple of 8.
+ * set_filter copies host memory to HBM; set_filter_device adopts a device
+ * pointer owned by the caller (e.g. a buffer that was just RCCL-broadcast). */
+int ntedit_hip_set_filter(
+    ntedit_hip_ctx* ctx,
+    int slot,
+    const uint8_t* bits,
+    uint64_t nbytes,
+    uint32_t hash_num,
+    uint32_t k,
+    int counting);
+int ntedit_hip_set_filter_device(
+    ntedit_hip_ctx* ctx,
+    int slot,
+    void* device_bits,
+    uint64_t nbytes,
+    uint32_t hash_num,
+    uint32_t k,
+    int counting);
+/* reads a btllib-format .bf file (header + raw array) straight into HBM */
+int ntedit_hip_load_filter_file(ntedit_hip_ctx* ctx, int slot, const char* path);
+/* filter geometry as loaded: k, hash_num, bytes, counting */
+int ntedit_hip_filter_info(
+    const ntedit_hip_ctx* ctx,
+    int slot,
+    uint32_t* k,
+    uint32_t* hash_num,
+    uint64_t* nbytes,
+    int* counting);
+void* ntedit_hip_filter_device_ptr(const ntedit_hip_ctx* ctx, int slot);
+
+/* Build side (fixtures / benchmarks; mirrors src/ntedit_make_genome_bf.cpp:143-157):
+ * allocate a zeroed filter in HBM, insert every all-ACGT k-mer of a sequence,
+ * download / save it. */
+int ntedit_hip_filter_alloc(ntedit_hip_ctx* ctx, int slot, uint64_t nbytes, uint32_t hash_num, uint32_t k);
+int ntedit_hip_filter_insert(ntedit_hip_ctx* ctx, int slot, const char* bases, uint64_t n, int on_device);
+int ntedit_hip_filter_download(const ntedit_hip_ctx* ctx, int slot, uint8_t* bits);
+int ntedit_hip_filter_save_file(const ntedit_hip_ctx* ctx, int slot, const char* path);
+
+int ntedit_hip_set_params(ntedit_hip_ctx* ctx, const ntedit_hip_params* p);
+
+/* ---- hot path ------------------------------------------------------------
+ * Batch layout: `bases` holds the contigs of the batch; contig i occupies
+ * bases[offsets[i] .. offsets[i]+lens[i]) and every contig is followed by at
+ * least one byte that is not an accepted base (the host driver uses '\n').
+ * n = total bytes.  on_device != 0 means `bases` is already in HBM. */
+
+/* step 1 only (ntedit.cpp:1798-1807): bit i of bitmap (ceil(n/64) words,
+ * host memory, or device memory when on_device) is set iff the k-mer starting
+ * at byte i consists of accepted bases only and is NOT in the primary filter. */
+int ntedit_hip_screen(
+    ntedit_hip_ctx* ctx,
+    const char* bases,
+    uint64_t n,
+    int on_device,
+    uint64_t* bitmap);
+
+/* steps 1-5 + makeEdit for every contig of the batch.  The result holds the
+ * edit records; render it with ntedit_hip_write_outputs(). */
+int ntedit_hip_polish_batch(
+    ntedit_hip_ctx* ctx,
+    const char* bases,
+    uint64_t n,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    uint32_t n_contigs,
+    int on_device,
+    ntedit_hip_result** out);
+void ntedit_hip_result_free(ntedit_hip_result* r);
+
+typedef struct ntedit_hip_stats
+{
+	uint64_t bases;          /* bytes screened                               */
+	uint64_t absent_kmers;   /* set bits in the screening bitmap             */
+	uint64_t events;         /* event threads launched                       */
+	uint64_t events_applied; /* events that survive the serial-order filter  */
+	uint64_t substitutions, insertions, deletions; /* rope/record counts     */
+	float ms_screen;         /* HIP-event time of the screening kernel       */
+	float ms_extract;        /* event extraction kernels                     */
+	float ms_machine;        /* event machine kernel                         */
+	float ms_total;          /* first kernel start -> last kernel end        */
+} ntedit_hip_stats;
+int ntedit_hip_result_stats(const ntedit_hip_result* r, ntedit_hip_stats* s);
+
+/* Host-side rendering of a result (replaces writeEditsToFile, ntedit.cpp:925-1213,
+ * for _edited.fa and _changes.tsv; the VCF body is outside the parity contract).
+ * bases/offsets/lens: the same batch, in HOST memory.  names[i] is the FASTA
+ * header text (name + " " + comment, ntedit.cpp:2224-2229).  Files are opened
+ * in append mode when append != 0; the TSV header is written by
+ * ntedit_hip_write_tsv_header(). */
+int ntedit_hip_write_outputs(
+    const ntedit_hip_result* r,
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    const char* fa_path,
+    const char* tsv_path,
+    int append);
+int ntedit_hip_write_tsv_header(const char* tsv_path, uint32_t k, uint32_t jump, int counting);
+
+/* timings of the last screen()/filter_insert() call (HIP events, ms) */
+float ntedit_hip_last_kernel_ms(const ntedit_hip_ctx* ctx);
+
+/* random 1-byte gather micro-benchmark over a filter-sized buffer: the
+ * "HBM random-read roofline" denominator of SURVEY.md 8(d).  Returns probes/s. */
+int ntedit_hip_gather_bench(ntedit_hip_ctx* ctx, uint64_t nbytes, uint64_t n_probes, double* probes_per_s, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,304 @@
+// nte_common.h -- shared definitions for the MI355X ntEdit hot path:
+// ntHash2 arithmetic, Bloom-filter probe, device-side parameter block and the
+// event-record wire format.  Compiles under hipcc (device + host) and under a
+// plain host compiler (used by the CPU-side logic tests of the event machine).
+//
+// Reference behaviour restated here (never copied):
+//   btllib hashing_internals (call sites ntedit.cpp:412-415,428-431,444-451)
+//   btllib KmerBloomFilter::contains (call site ntedit.cpp:368-371)
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define NTE_HD __host__ __device__ __forceinline__
+#else
+#define NTE_HD inline
+#endif
+
+namespace nte {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---------------------------------------------------------------- constants
+// ntHash2 seeds; SEED_N = 0.
+constexpr u64 SEED_A = 0x3c8bfbb395c60474ULL;
+constexpr u64 SEED_C = 0x3193c18562a02b4cULL;
+constexpr u64 SEED_G = 0x20323ed082572324ULL;
+constexpr u64 SEED_T = 0x295549f54be24456ULL;
+constexpr u64 MULTISEED = 0x90b45d39fb6da1faULL;
+constexpr unsigned MULTISHIFT = 27;
+constexpr unsigned MAX_HASHES = 8;
+
+// Character classes.  Every byte of the draft is mapped to a 4-bit code:
+//   0..3   A C G T (either case)
+//   4..13  the other "accepted" IUPAC codes R Y S W K M B D H V
+//          (isAcceptedBase, ntedit.cpp:493-499; case-insensitive via toupper)
+//   15     anything else (N, U, separators): breaks every k-mer it touches
+constexpr u8 CODE_BAD = 15;
+
+NTE_HD u8
+char_code(u8 c)
+{
+	switch (c & 0xDF) { // folds a-z onto A-Z; no other byte lands on a letter
+	case 'A':
+		return 0;
+	case 'C':
+		return 1;
+	case 'G':
+		return 2;
+	case 'T':
+		return 3;
+	case 'R':
+		return 4;
+	case 'Y':
+		return 5;
+	case 'S':
+		return 6;
+	case 'W':
+		return 7;
+	case 'K':
+		return 8;
+	case 'M':
+		return 9;
+	case 'B':
+		return 10;
+	case 'D':
+		return 11;
+	case 'H':
+		return 12;
+	case 'V':
+		return 13;
+	default:
+		return CODE_BAD;
+	}
+}
+
+// Forward seed of a code = SEED_TAB[letter]; only ACGT are non-zero.
+NTE_HD u64
+seed_fwd_of_code(u8 code)
+{
+	switch (code) {
+	case 0:
+		return SEED_A;
+	case 1:
+		return SEED_C;
+	case 2:
+		return SEED_G;
+	case 3:
+		return SEED_T;
+	default:
+		return 0;
+	}
+}
+
+// Reverse-strand seed = SEED_TAB[letter & 7] (CP_OFF slots 1,3,4,5,7 hold the
+// complement seeds).  For the IUPAC letters the slot is whatever (c & 7)
+// lands on: Y->1(T) S->3(G) W->7(C) K->3(G) M->5(A) D->4(A), R/B/H/V -> 0.
+NTE_HD u64
+seed_rev_of_code(u8 code)
+{
+	switch (code) {
+	case 0: // A -> T
+		return SEED_T;
+	case 1: // C -> G
+		return SEED_G;
+	case 2: // G -> C
+		return SEED_C;
+	case 3: // T -> A
+		return SEED_A;
+	case 5: // Y (0x59 & 7 = 1)
+		return SEED_T;
+	case 6: // S (0x53 & 7 = 3)
+		return SEED_G;
+	case 7: // W (0x57 & 7 = 7)
+		return SEED_C;
+	case 8: // K (0x4B & 7 = 3)
+		return SEED_G;
+	case 9: // M (0x4D & 7 = 5)
+		return SEED_A;
+	case 11: // D (0x44 & 7 = 4)
+		return SEED_A;
+	default: // R B H V and BAD
+		return 0;
+	}
+}
+
+// ---------------------------------------------------------------- rotations
+// ntHash2 "split rotate": bits 0..32 and bits 33..63 rotate independently.
+NTE_HD u64
+srol1(u64 x)
+{
+	u64 m = ((x & 0x8000000000000000ULL) >> 30) | ((x & 0x100000000ULL) >> 32);
+	return ((x << 1) & 0xFFFFFFFDFFFFFFFFULL) | m;
+}
+
+NTE_HD u64
+sror1(u64 x)
+{
+	u64 m = ((x & 0x200000000ULL) << 30) | ((x & 1ULL) << 32);
+	return ((x >> 1) & 0xFFFFFFFEFFFFFFFFULL) | m;
+}
+
+NTE_HD u64
+sroln(u64 x, unsigned d)
+{
+	const u64 lo_mask = 0x1FFFFFFFFULL;
+	u64 lo = x & lo_mask;
+	u64 hi = x >> 33;
+	unsigned dl = d % 33, dh = d % 31;
+	if (dl) {
+		lo = ((lo << dl) | (lo >> (33 - dl))) & lo_mask;
+	}
+	if (dh) {
+		hi = ((hi << dh) | (hi >> (31 - dh))) & 0x7FFFFFFFULL;
+	}
+	return (hi << 33) | lo;
+}
+
+// ------------------------------------------------------------- seed tables
+// Five 16-entry tables indexed by character code, rebuilt per k:
+//   F   forward seed                      (enters the forward hash)
+//   FK  forward seed rotated by k         (leaves the forward hash)
+//   R   reverse seed                      (leaves the reverse hash)
+//   RK  reverse seed rotated by k         (enters the reverse hash)
+//   RK1 reverse seed rotated by k-1       (swap of the LAST base, ntedit.cpp:434-452)
+enum
+{
+	TAB_F = 0,
+	TAB_FK = 16,
+	TAB_R = 32,
+	TAB_RK = 48,
+	TAB_RK1 = 64,
+	TAB_WORDS = 80
+};
+
+inline void
+build_seed_tables(unsigned k, u64* tab)
+{
+	for (u8 c = 0; c < 16; c++) {
+		u64 f = seed_fwd_of_code(c), r = seed_rev_of_code(c);
+		tab[TAB_F + c] = f;
+		tab[TAB_FK + c] = sroln(f, k);
+		tab[TAB_R + c] = r;
+		tab[TAB_RK + c] = sroln(r, k);
+		tab[TAB_RK1 + c] = sroln(r, k - 1);
+	}
+}
+
+struct HashState
+{
+	u64 fh, rh;
+};
+
+// roll one base: `out` leaves at the head, `in` enters at the tail
+NTE_HD void
+hash_roll(HashState& s, const u64* tab, u8 out, u8 in)
+{
+	s.fh = srol1(s.fh) ^ tab[TAB_F + in] ^ tab[TAB_FK + out];
+	s.rh = sror1(s.rh ^ tab[TAB_RK + in] ^ tab[TAB_R + out]);
+}
+
+// replace the last base of the current k-mer
+NTE_HD void
+hash_changelast(HashState& s, const u64* tab, u8 out, u8 in)
+{
+	s.fh ^= tab[TAB_F + out] ^ tab[TAB_F + in];
+	s.rh ^= tab[TAB_RK1 + out] ^ tab[TAB_RK1 + in];
+}
+
+// --------------------------------------------------------------- the filter
+struct Filter
+{
+	const u8* data; // bit array (plain BF), LSB-first within a byte
+	u64 bits;       // array size in bits (= bytes * 8)
+	u64 mask;       // bits - 1 when bits is a power of two, else 0
+	u32 hash_num;
+	u32 pad;
+};
+
+struct DevParams
+{
+	u32 k, h;
+	u32 jump;
+	u32 ins_tries;     // num_tries[max_insertions] (ntedit.cpp:172,1587)
+	u32 max_deletions;
+	u32 mode, mask, secbf;
+	u32 insertion_cap;
+	// the float comparisons of ntedit.cpp:1531-1535,1659-1663,1867-1872,1992-1997
+	// folded on the host into "count >= integer" thresholds
+	u32 thr_missing, thr_edit, thr_edit_del;
+	u32 start_grid;    // extra event start every start_grid positions inside an absent run
+	u32 node_window;   // live rope nodes kept per event thread
+	u64 mul[MAX_HASHES]; // mul[i] = i ^ (k * MULTISEED), i >= 1
+};
+
+NTE_HD u64
+hash_extend(u64 base, const DevParams& p, unsigned i)
+{
+	if (i == 0) {
+		return base;
+	}
+	u64 t = base * p.mul[i];
+	return t ^ (t >> MULTISHIFT);
+}
+
+NTE_HD u64
+filter_slot(const Filter& f, u64 hv)
+{
+	return f.mask ? (hv & f.mask) : (hv % f.bits);
+}
+
+// contains(): AND of hash_num bits, early exit on the first zero
+NTE_HD bool
+filter_contains(const Filter& f, const DevParams& p, const HashState& s)
+{
+	u64 base = s.fh + s.rh;
+	for (unsigned i = 0; i < f.hash_num; i++) {
+		u64 n = filter_slot(f, hash_extend(base, p, i));
+		if (!((f.data[n >> 3] >> (n & 7)) & 1)) {
+			return false;
+		}
+	}
+	return true;
+}
+
+// ------------------------------------------------------- event wire format
+// Event threads stream 16-byte items into 128-byte chunks of a global arena.
+// chunk = 8 items; item 0 is the chunk link {next, n_items, -, -}; the first
+// chunk of an event carries the event header in item 1.
+constexpr u32 CHUNK_ITEMS = 8;
+constexpr u32 NONE32 = 0xFFFFFFFFu;
+
+enum ItemTag : u32
+{
+	TAG_NODE = 1,
+	TAG_SUB = 2,
+	TAG_MOD = 3,
+	TAG_HDR = 4
+};
+
+enum EventFlags : u32
+{
+	EV_TERMINAL = 1,  // ran to the end of the contig
+	EV_OVERFLOW = 2   // ran out of node window / arena: results invalid
+};
+
+struct Item
+{
+	u32 w[4];
+};
+
+// rope node (ntedit.cpp:613-620), packed
+struct Node
+{
+	u32 s_pos, e_pos;
+	u16 support;
+	int8_t type; // -1 unset, 0 position range, 1 character
+	u8 c;
+};
+
+} // namespace nte

@@ -1,0 +1,1306 @@
+// nte_machine.h -- the per-event edit-search state machine.
+//
+// One event = one "absent" k-mer start found by the screening kernel.  The
+// machine restates, for a thread that starts in a CLEAN state (no earlier edit
+// inside its k-mer window), exactly what the reference's strictly serial
+// per-contig loop does from that position on (ntedit.cpp:1798-2139): confirm
+// the k-mer is missing on a k/j subset (step 2), sweep substitution candidates
+// (step 3), sweep insertion / deletion candidates (steps 4-5, tryIndels /
+// tryDeletion ntedit.cpp:1451-1744), apply the best edit to the edited-sequence
+// rope (makeEdit 1250-1448 with makeInsertion 625-714 / makeDeletion 719-809),
+// and keep rolling while the window still overlaps an edit.  It stops as soon
+// as it is clean again and the next position belongs to another event (or is
+// present in the filter), reporting how far it got ("cover_end"); the host
+// drops every speculative event that starts below an earlier event's
+// cover_end, which reproduces the reference's serial order exactly.
+//
+// Design notes (MI355X): one thread per event; the rope is a small sliding
+// window of nodes in a per-thread global workspace (finalised nodes are
+// streamed out), modified draft characters live in a tiny overlay, all output
+// goes through 16-byte items appended to 128-byte chunks of a global arena.
+// The same source compiles for the host so the control logic can be tested
+// without a GPU (tests/hostsim) -- that build is test-only and is not part of
+// the shipped library.
+#pragma once
+#include "nte_common.h"
+
+namespace nte {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NTE_ATOMIC_INC(p) atomicAdd((p), 1u)
+#else
+#define NTE_ATOMIC_INC(p) ((*(p))++)
+#endif
+
+constexpr u32 PREV_CAP = 512; // longest run of inserted characters examined (>= 1.5k + 16)
+
+struct EventEnv
+{
+	const u8* seq;  // contig bases
+	u32 len;
+	u32 contig;
+	u64 gbase;      // global index of seq[0] in the batch (bitmap coordinates)
+	const u64* bitmap;
+	const u64* tab; // seed tables (LDS on the device)
+	const DevParams* p;
+	Filter bloom, rep;
+	// per-thread workspace
+	Node* nodes;
+	u32* ov_pos;
+	u8* ov_chr;
+	// output arena
+	Item* arena;
+	u32* arena_next;
+	u32 arena_chunks;
+};
+
+NTE_HD bool
+bit_absent(const u64* bitmap, u64 g)
+{
+	return (bitmap[g >> 6] >> (g & 63)) & 1;
+}
+
+// event-start predicate shared by the extraction kernel and the machine
+NTE_HD bool
+is_event_start(const u64* bitmap, u64 g, u32 grid)
+{
+	if (!bit_absent(bitmap, g)) {
+		return false;
+	}
+	if (g == 0 || !bit_absent(bitmap, g - 1)) {
+		return true;
+	}
+	return (g % grid) == 0;
+}
+
+struct Best
+{
+	u32 edit_type; // 0 none, 1 substitution, 2 insertion, 3 deletion
+	u8 indel[12];
+	u32 n_indel;
+	u8 sub_base;
+	u32 num_support;
+	u8 altbase1, altbase2, altbase3;
+	u32 altsupp1, altsupp2, altsupp3;
+};
+
+struct Machine
+{
+	const EventEnv& e;
+	const DevParams& p;
+	// cursors (ntedit.cpp:1773-1795)
+	u32 h_seq_i, t_seq_i, h_node, t_node;
+	HashState hs;
+	// rope window
+	u32 nbase, nsize;
+	bool rope_touched;
+	// overlay of modified draft characters
+	u32 n_ov;
+	bool tmp_on;
+	u32 tmp_pos;
+	u8 tmp_chr;
+	int64_t last_sub_pos; // right-most substituted draft position so far
+	// output
+	u32 first_chunk, cur_chunk, fill;
+	u32 flags;
+
+	NTE_HD
+	Machine(const EventEnv& env)
+	  : e(env)
+	  , p(*env.p)
+	{
+	}
+
+	// ------------------------------------------------------------ output
+	NTE_HD void
+	emit(const Item& it)
+	{
+		if (flags & EV_OVERFLOW) {
+			return;
+		}
+		if (cur_chunk == NONE32 || fill == CHUNK_ITEMS) {
+			u32 c = NTE_ATOMIC_INC(e.arena_next);
+			if (c >= e.arena_chunks) {
+				flags |= EV_OVERFLOW;
+				return;
+			}
+			if (cur_chunk == NONE32) {
+				first_chunk = c;
+				fill = 2; // link + event header
+			} else {
+				Item link;
+				link.w[0] = c;
+				link.w[1] = fill;
+				link.w[2] = link.w[3] = 0;
+				e.arena[(u64)cur_chunk * CHUNK_ITEMS] = link;
+				fill = 1;
+			}
+			cur_chunk = c;
+		}
+		e.arena[(u64)cur_chunk * CHUNK_ITEMS + fill] = it;
+		fill++;
+	}
+
+	NTE_HD void
+	emit_node(const Node& n)
+	{
+		Item it;
+		it.w[0] = TAG_NODE | ((u32)(u8)n.type << 8) | ((u32)n.c << 16);
+		it.w[1] = n.s_pos;
+		it.w[2] = n.e_pos;
+		it.w[3] = n.support;
+		emit(it);
+	}
+
+	NTE_HD void
+	emit_mod(u32 pos, u8 c)
+	{
+		Item it;
+		it.w[0] = TAG_MOD | ((u32)c << 8);
+		it.w[1] = pos;
+		it.w[2] = it.w[3] = 0;
+		emit(it);
+	}
+
+	// ------------------------------------------------------- rope window
+	NTE_HD Node
+	unset_node() const
+	{
+		Node n;
+		n.s_pos = n.e_pos = 0;
+		n.support = 0;
+		n.type = -1;
+		n.c = 0;
+		return n;
+	}
+
+	NTE_HD Node
+	nget(u32 idx) const
+	{
+		if (idx >= nsize || idx < nbase) {
+			return unset_node(); // (U1) reads past the end give an unset node
+		}
+		return e.nodes[idx - nbase];
+	}
+
+	NTE_HD void
+	nset(u32 idx, const Node& n)
+	{
+		if (idx < nbase) {
+			flags |= EV_OVERFLOW; // would touch an already streamed-out node
+			return;
+		}
+		e.nodes[idx - nbase] = n;
+	}
+
+	NTE_HD void
+	nput(u32 idx, const Node& n)
+	{
+		// "assign if idx < size else push_back" idiom of the reference
+		if (idx < nsize) {
+			nset(idx, n);
+		} else {
+			if (nsize - nbase >= p.node_window) {
+				flags |= EV_OVERFLOW;
+				return;
+			}
+			e.nodes[nsize - nbase] = n;
+			nsize++;
+		}
+	}
+
+	NTE_HD void
+	set_type(u32 idx, int8_t t)
+	{
+		if (idx >= nbase && idx < nsize) {
+			e.nodes[idx - nbase].type = t;
+		}
+	}
+
+	// stream out rope nodes that can no longer be touched
+	NTE_HD void
+	housekeeping()
+	{
+		if (nsize - nbase + 40 > p.node_window) {
+			u32 keep = h_node < t_node ? h_node : t_node;
+			while (keep > nbase && nget(keep - 1).type == 1) {
+				keep--;
+			}
+			if (keep > nbase) {
+				keep--; // the position node in front of the run (see drop_prev_insertion)
+			}
+			if (keep > nbase) {
+				for (u32 i = nbase; i < keep; i++) {
+					emit_node(e.nodes[i - nbase]);
+				}
+				u32 n = nsize - keep;
+				for (u32 i = 0; i < n; i++) {
+					e.nodes[i] = e.nodes[i + (keep - nbase)];
+				}
+				nbase = keep;
+			}
+			if (nsize - nbase + 24 > p.node_window) {
+				flags |= EV_OVERFLOW;
+			}
+		}
+		if (n_ov + 8 > p.node_window) {
+			u32 w = 0;
+			for (u32 i = 0; i < n_ov; i++) {
+				if (e.ov_pos[i] >= h_seq_i) {
+					e.ov_pos[w] = e.ov_pos[i];
+					e.ov_chr[w] = e.ov_chr[i];
+					w++;
+				}
+			}
+			n_ov = w;
+			if (n_ov + 8 > p.node_window) {
+				flags |= EV_OVERFLOW;
+			}
+		}
+	}
+
+	// -------------------------------------------------- draft characters
+	NTE_HD u8
+	seq_at(u32 pos) const
+	{
+		if (pos >= e.len) {
+			return 0; // contigSeq.at() would throw; unreachable in practice
+		}
+		if (tmp_on && pos == tmp_pos) {
+			return tmp_chr;
+		}
+		for (u32 i = n_ov; i > 0; i--) {
+			if (e.ov_pos[i - 1] == pos) {
+				return e.ov_chr[i - 1];
+			}
+		}
+		return e.seq[pos];
+	}
+
+	NTE_HD void
+	set_seq(u32 pos, u8 c)
+	{
+		for (u32 i = 0; i < n_ov; i++) {
+			if (e.ov_pos[i] == pos) {
+				if (e.ov_chr[i] != c) {
+					e.ov_chr[i] = c;
+					emit_mod(pos, c);
+				}
+				return;
+			}
+		}
+		if (e.seq[pos] == c) {
+			return;
+		}
+		if (n_ov < p.node_window) {
+			e.ov_pos[n_ov] = pos;
+			e.ov_chr[n_ov] = c;
+			n_ov++;
+		} else {
+			flags |= EV_OVERFLOW;
+		}
+		emit_mod(pos, c);
+	}
+
+	// ntedit.cpp:812-823
+	NTE_HD u8
+	get_character(u32 pos, const Node& n) const
+	{
+		if (n.type == 0) {
+			return seq_at(pos);
+		}
+		if (n.type == 1) {
+			return n.c;
+		}
+		return 0;
+	}
+
+	// ntedit.cpp:826-844
+	NTE_HD void
+	increment(u32& pos, u32& node_index) const
+	{
+		Node n = nget(node_index);
+		if (n.type == 0) {
+			pos++;
+			if (pos > n.e_pos) {
+				node_index++;
+				Node nx = nget(node_index);
+				if (nx.type == 0) {
+					pos = nx.s_pos;
+				}
+			}
+		} else if (n.type == 1) {
+			node_index++;
+			Node nx = nget(node_index);
+			if (nx.type == 0) {
+				pos = nx.s_pos;
+			}
+		}
+	}
+
+	// ntedit.cpp:1216-1247
+	NTE_HD bool
+	roll(u32& hs_i, u32& ts_i, u32& hn, u32& tn, u8& char_out, u8& char_in) const
+	{
+		if (hs_i >= e.len || hn >= nsize) {
+			return false;
+		}
+		char_out = get_character(hs_i, nget(hn));
+		increment(hs_i, hn);
+		if (ts_i >= e.len || tn >= nsize) {
+			return false;
+		}
+		increment(ts_i, tn);
+		if (ts_i >= e.len || tn >= nsize) {
+			return false;
+		}
+		char_in = get_character(ts_i, nget(tn));
+		return true;
+	}
+
+	// --------------------------------------------------------- filters
+	NTE_HD bool
+	in_bloom(const HashState& s) const
+	{
+		return filter_contains(e.bloom, p, s);
+	}
+
+	// is_kmer_solid (ntedit.cpp:465-473), plain-filter form
+	NTE_HD bool
+	solid(const HashState& s) const
+	{
+		return !p.secbf || !filter_contains(e.rep, p, s);
+	}
+
+	NTE_HD bool
+	present_solid(const HashState& s) const
+	{
+		return in_bloom(s) && solid(s);
+	}
+
+	NTE_HD void
+	roll_hash(HashState& s, u8 char_out, u8 char_in) const
+	{
+		hash_roll(s, e.tab, char_code(char_out), char_code(char_in));
+	}
+
+	NTE_HD void
+	changelast(HashState& s, u8 char_out, u8 char_in) const
+	{
+		hash_changelast(s, e.tab, char_code(char_out), char_code(char_in));
+	}
+
+	// ------------------------------------------------ rope edit primitives
+	// ntedit.cpp:625-714
+	NTE_HD void
+	make_insertion(u32& tn, u32 insert_pos, const u8* ins, u32 n_ins, u32 support)
+	{
+		rope_touched = true;
+		Node orig = nget(tn);
+		Node cn;
+		cn.s_pos = cn.e_pos = 0;
+		cn.type = 1;
+		cn.support = (u16)support;
+		if ((orig.type == 0 && insert_pos <= orig.s_pos) || orig.type == 1) {
+			// shift the run of valid nodes starting at tn right by n_ins
+			u32 end = tn;
+			while (end < nsize && nget(end).type != -1) {
+				end++;
+			}
+			u32 n_re = end - tn;
+			for (u32 q = n_re; q > 0; q--) {
+				nput(tn + n_ins + q - 1, nget(tn + q - 1));
+			}
+			for (u32 q = 0; q < n_ins; q++) {
+				cn.c = ins[q];
+				nput(tn + q, cn);
+			}
+		} else if (orig.type == 0) {
+			Node after;
+			after.type = 0;
+			after.s_pos = insert_pos;
+			after.e_pos = orig.e_pos;
+			after.c = 0;
+			after.support = 0;
+			orig.e_pos = insert_pos - 1;
+			nset(tn, orig);
+			for (u32 q = 0; q < n_ins; q++) {
+				cn.c = ins[q];
+				nput(tn + q + 1, cn);
+			}
+			nput(tn + n_ins + 1, after);
+			tn++;
+		}
+	}
+
+	// ntedit.cpp:719-809 (the reference recurses on the leftover; here a loop)
+	NTE_HD void
+	make_deletion(u32& tn, u32& pos, u32 num_del, u32 support)
+	{
+		rope_touched = true;
+		while (true) {
+			Node orig = nget(tn);
+			u32 leftover = 0;
+			if (orig.type == 0) {
+				if (pos <= orig.s_pos) {
+					if ((u64)pos + num_del <= orig.e_pos) {
+						// deleting off the beginning of a position node
+						orig.s_pos = pos + num_del;
+						orig.support = (u16)support;
+						nset(tn, orig);
+						pos = orig.s_pos;
+						return;
+					}
+					// the whole position node goes; later nodes move down one slot
+					leftover = (u32)((u64)pos + num_del - orig.e_pos);
+					pos = orig.e_pos + 1;
+					u32 i = tn + 1;
+					while (i < nsize && nget(i).type != -1) {
+						nset(i - 1, nget(i));
+						set_type(i, -1);
+						i++;
+					}
+				} else {
+					if ((u64)pos + num_del <= orig.e_pos) {
+						// deleting in the middle of a position node: split it
+						Node split;
+						split.type = 0;
+						split.s_pos = pos + num_del;
+						split.e_pos = orig.e_pos;
+						split.c = 0;
+						split.support = (u16)support;
+						Node front = orig;
+						front.e_pos = pos - 1;
+						nset(tn, front);
+						pos = split.s_pos;
+						tn++;
+						nput(tn, split);
+						return;
+					}
+					// from the middle of a position node past its end
+					leftover = (u32)((u64)pos + num_del - orig.e_pos);
+					Node front = orig;
+					front.e_pos = pos - 1;
+					nset(tn, front);
+					pos = orig.e_pos + 1;
+					tn++;
+				}
+			} else if (orig.type == 1) {
+				u32 i = tn;
+				leftover = num_del;
+				while (i < nsize && nget(i).type == 1 && leftover > 0) {
+					set_type(i, -1);
+					leftover--;
+					i++;
+				}
+				u32 j = tn;
+				while (i < nsize && nget(i).type != -1) {
+					nset(j, nget(i));
+					set_type(i, -1);
+					i++;
+					j++;
+				}
+			} else {
+				return;
+			}
+			if (leftover == 0) {
+				return;
+			}
+			Node nx = nget(tn);
+			if (!(tn < nsize && nx.type != -1)) {
+				return;
+			}
+			if (nx.type == 0) {
+				pos = nx.s_pos;
+			}
+			num_del = leftover; // pass the rest of the deletion to the next node
+		}
+	}
+
+	// ntedit.cpp:848-903.  Instead of returning the k-mer string the hash of it
+	// is accumulated directly (seed of ntedit.cpp:412-413).  Returns false (and
+	// h = t = len, hash of an all-zero-seed string) when no k-mer is left.
+	NTE_HD bool
+	find_accepted_kmer()
+	{
+		u32 temp_t_node = t_node;
+		Node curr = nget(t_node);
+		u32 i = t_seq_i;
+		while (i < e.len && temp_t_node < nsize && nget(temp_t_node).type != -1) {
+			u8 c = get_character(i, curr);
+			if (char_code(c) != CODE_BAD) {
+				u32 n = 1;
+				u8 code = char_code(c);
+				u64 fh = e.tab[TAB_F + code];
+				u64 rh = e.tab[TAB_R + code];
+				u32 temp_h_node = temp_t_node;
+				u32 j = i;
+				increment(j, temp_t_node);
+				while (j < e.len && temp_t_node < nsize && nget(temp_t_node).type != -1) {
+					curr = nget(temp_t_node);
+					c = get_character(j, curr);
+					code = char_code(c);
+					if (code == CODE_BAD) {
+						i = j;
+						break;
+					}
+					fh = srol1(fh) ^ e.tab[TAB_F + code];
+					rh ^= sroln(e.tab[TAB_R + code], n);
+					n++;
+					if (n == p.k) {
+						break;
+					}
+					increment(j, temp_t_node);
+				}
+				if (n == p.k) {
+					h_seq_i = i;
+					t_seq_i = j;
+					h_node = temp_h_node;
+					t_node = temp_t_node;
+					hs.fh = fh;
+					hs.rh = rh;
+					return true;
+				}
+			}
+			increment(i, temp_t_node);
+		}
+		h_seq_i = e.len;
+		t_seq_i = e.len;
+		hs.fh = 0;
+		hs.rh = 0;
+		return false;
+	}
+
+	// ntedit.cpp:501-520
+	NTE_HD static u8
+	rc_char(u8 c)
+	{
+		switch (c) {
+		case 'A':
+		case 'a':
+			return 'T';
+		case 'T':
+		case 't':
+			return 'A';
+		case 'G':
+		case 'g':
+			return 'C';
+		case 'C':
+		case 'c':
+			return 'G';
+		default:
+			return 'N';
+		}
+	}
+
+	// ntedit.cpp:907-922
+	NTE_HD u32
+	get_prev_insertion(u8* out) const
+	{
+		u32 n = 0;
+		u32 idx = t_node;
+		Node tn = nget(idx);
+		if ((idx < nsize && tn.type == 0 && t_seq_i == tn.s_pos) || tn.type == 1) {
+			idx--;
+		}
+		while (idx < nsize && idx >= nbase && nget(idx).type == 1) {
+			if (n < PREV_CAP) {
+				out[n] = rc_char(nget(idx).c);
+			}
+			n++;
+			idx--;
+		}
+		return n;
+	}
+
+	// ntedit.cpp:561-596: is s a whole-number repetition of a shorter word?
+	NTE_HD static bool
+	is_repeat(const u8* s, int n, int16_t* lps)
+	{
+		if (n <= 0) {
+			return false;
+		}
+		int len = 0, i = 1;
+		lps[0] = 0;
+		while (i < n) {
+			if (s[i] == s[len]) {
+				len++;
+				lps[i] = (int16_t)len;
+				i++;
+			} else if (len != 0) {
+				len = lps[len - 1];
+			} else {
+				lps[i] = 0;
+				i++;
+			}
+		}
+		len = lps[n - 1];
+		return len > 0 && n % (n - len) == 0;
+	}
+
+	// ntedit.cpp:1321-1334 / 1352-1366: pull the nodes behind the tail over
+	// the previous run of inserted characters
+	NTE_HD void
+	drop_prev_insertion(u32 count)
+	{
+		rope_touched = true;
+		u32 j = 1;
+		Node tn = nget(t_node);
+		if (tn.type == 0 && t_seq_i == tn.s_pos) {
+			j = 0;
+		}
+		for (u32 i = count; i > 0; i--) {
+			u32 dst = t_node - i; // wraps like the reference when i > t_node
+			Node src = nget(t_node + j);
+			if (t_node + j < nsize && src.type != -1) {
+				if (dst < nsize) {
+					nset(dst, src);
+				}
+				set_type(t_node + j, -1);
+				j++;
+			} else if (dst < nsize) {
+				if (dst < nbase) {
+					flags |= EV_OVERFLOW;
+				}
+				set_type(dst, -1);
+			}
+		}
+	}
+
+	// i-th insertion candidate behind an index base: the index base followed by
+	// every word over A<C<G<T of length 0..4 in length-then-lexicographic order
+	// (the enumeration of ntedit.cpp:203-348, generated instead of stored)
+	NTE_HD static u32
+	insertion_candidate(u8 index_char, u32 i, u8* out)
+	{
+		u32 extra = 0, first = 0, count = 1;
+		while (i >= first + count) {
+			first += count;
+			count *= 4;
+			extra++;
+		}
+		u32 r = i - first;
+		out[0] = index_char;
+		for (u32 q = 0; q < extra; q++) {
+			u32 d = r & 3;
+			out[extra - q] = d == 0 ? 'A' : d == 1 ? 'C' : d == 2 ? 'G' : 'T';
+			r >>= 2;
+		}
+		return extra + 1;
+	}
+
+	// ntedit.cpp:1451-1545; returns the support (0 = rejected)
+	NTE_HD u32
+	try_deletion(u8 draft_char, u32 num_deletions, u8* deleted, u32& n_deleted)
+	{
+		HashState ts = hs;
+		u32 th = h_seq_i, tt = t_seq_i, thn = h_node, ttn = t_node;
+		u8 char_out = 0, char_in = 0;
+		n_deleted = 0;
+		for (u32 i = 0; i < num_deletions; i++) {
+			deleted[n_deleted++] = get_character(tt, nget(ttn));
+			increment(tt, ttn);
+		}
+		changelast(ts, draft_char, get_character(tt, nget(ttn)));
+		u32 check_present = 0;
+		if (present_solid(ts)) {
+			check_present++;
+		}
+		for (u32 k = 1; k <= (p.k - 2) && th < e.len; k++) {
+			if (roll(th, tt, thn, ttn, char_out, char_in)) {
+				roll_hash(ts, char_out, char_in);
+				if (k % p.jump == 0 && present_solid(ts)) {
+					check_present++;
+				}
+			}
+		}
+		return check_present >= p.thr_edit_del ? check_present : 0;
+	}
+
+	NTE_HD static void
+	copy_bytes(u8* dst, const u8* src, u32 n)
+	{
+		for (u32 i = 0; i < n; i++) {
+			dst[i] = src[i];
+		}
+	}
+
+	// ntedit.cpp:1548-1744
+	NTE_HD bool
+	try_indels(u8 draft_char, u8 index_char, u32& num_deletions, Best& b)
+	{
+		u32 temp_best_support = 0, temp_alt_support = 0;
+		u8 temp_best_indel[12];
+		u32 temp_best_n = 0;
+		u32 temp_best_type = 0;
+		u8 char_in = 0, char_out = 0;
+
+		for (u32 i = 0; i < p.ins_tries; i++) {
+			u8 ins[12];
+			u32 n_ins = insertion_candidate(index_char, i, ins);
+			ins[n_ins++] = draft_char;
+
+			HashState ts = hs;
+			u32 th = h_seq_i, tt = t_seq_i, thn = h_node, ttn = t_node;
+			changelast(ts, draft_char, index_char);
+			u32 check_present = 0;
+			u32 k = 0;
+			// k-mers that end inside the inserted bases
+			for (; k < n_ins - 1 && th < e.len; k++) {
+				roll_hash(ts, get_character(th, nget(thn)), ins[k + 1]);
+				increment(th, thn);
+				if (k % p.jump == 0 && present_solid(ts)) {
+					check_present++;
+				}
+			}
+			// k-mers that end behind the insertion
+			for (; k < p.k - 1 && th < e.len; k++) {
+				if (roll(th, tt, thn, ttn, char_out, char_in)) {
+					roll_hash(ts, char_out, char_in);
+					if (k % p.jump == 0 && present_solid(ts)) {
+						check_present++;
+					}
+				}
+			}
+			n_ins--; // drop the draft base again
+			if (check_present >= p.thr_edit) {
+				if (p.mode == 0) {
+					b.edit_type = 2;
+					copy_bytes(b.indel, ins, n_ins);
+					b.n_indel = n_ins;
+					b.num_support = check_present;
+					return true;
+				}
+				if (check_present >= temp_best_support) {
+					if (temp_best_support) {
+						temp_alt_support = temp_best_support;
+					}
+					temp_best_type = 2;
+					copy_bytes(temp_best_indel, ins, n_ins);
+					temp_best_n = n_ins;
+					temp_best_support = check_present;
+				}
+			}
+
+			if (num_deletions <= p.max_deletions) {
+				u8 deleted[12];
+				u32 n_deleted = 0;
+				u32 del_support = try_deletion(draft_char, num_deletions, deleted, n_deleted);
+				if (del_support > 0) {
+					if (p.mode == 0) {
+						b.edit_type = 3;
+						copy_bytes(b.indel, deleted, n_deleted);
+						b.n_indel = n_deleted;
+						b.num_support = del_support;
+						return true;
+					}
+					if (del_support >= temp_best_support) {
+						if (temp_best_support) {
+							temp_alt_support = temp_best_support;
+						}
+						temp_best_type = 3;
+						copy_bytes(temp_best_indel, deleted, n_deleted);
+						temp_best_n = n_deleted;
+						temp_best_support = del_support;
+					}
+				}
+				num_deletions++;
+			}
+		}
+
+		if (temp_best_support > 0) {
+			if ((p.mode == 2 && temp_best_support > b.num_support) || p.mode == 1) {
+				b.edit_type = temp_best_type;
+				copy_bytes(b.indel, temp_best_indel, temp_best_n);
+				b.n_indel = temp_best_n;
+				b.num_support = temp_best_support;
+				b.altsupp1 = temp_alt_support;
+			}
+			return true;
+		}
+		return false;
+	}
+
+	NTE_HD void
+	note_sub(u32 pos)
+	{
+		if ((int64_t)pos > last_sub_pos) {
+			last_sub_pos = pos;
+		}
+	}
+
+	NTE_HD void
+	reseed_after_skip()
+	{
+		// findAcceptedKmer + NTMC64 seed (ntedit.cpp:1335-1343); the hash of a
+		// missing k-mer is defined as 0 (the reference hashes "" there)
+		find_accepted_kmer();
+	}
+
+	// ntedit.cpp:1250-1448
+	NTE_HD void
+	make_edit(u8 draft_char, Best& b)
+	{
+		Node t_nd = nget(t_node);
+		switch (b.edit_type) {
+		case 1: {
+			if (t_nd.type == 0) {
+				set_seq(t_seq_i, b.sub_base);
+				note_sub(t_seq_i);
+				u8 a1 = 0, a2 = 0, a3 = 0;
+				u32 s1 = 0, s2 = 0, s3 = 0;
+				if (b.altsupp1 && b.altbase1 != b.sub_base) {
+					a1 = b.altbase1;
+					s1 = b.altsupp1;
+				}
+				if (b.altsupp2 && b.altbase2 != b.altbase1) {
+					a2 = b.altbase2;
+					s2 = b.altsupp2;
+				}
+				if (b.altsupp3 && b.altbase3 != b.altbase2) {
+					a3 = b.altbase3;
+					s3 = b.altsupp3;
+				}
+				Item it;
+				it.w[0] = TAG_SUB | ((u32)draft_char << 8) | ((u32)b.sub_base << 16) |
+				          ((b.num_support & 0xFF) << 24);
+				it.w[1] = t_seq_i;
+				it.w[2] = (u32)a1 | ((s1 & 0xFF) << 8) | ((u32)a2 << 16) | ((s2 & 0xFF) << 24);
+				it.w[3] = (u32)a3 | ((s3 & 0xFF) << 8);
+				emit(it);
+			} else if (t_nd.type == 1) {
+				t_nd.c = b.sub_base;
+				nset(t_node, t_nd);
+				rope_touched = true;
+				note_sub(t_seq_i);
+			}
+			changelast(hs, draft_char, b.sub_base);
+			break;
+		}
+		case 2: {
+			bool skipped_repeat = false;
+			u8 prev[PREV_CAP + 16];
+			int16_t lps[PREV_CAP + 16];
+			u32 n_prev = get_prev_insertion(prev);
+			if (n_prev + 12 > PREV_CAP) {
+				flags |= EV_OVERFLOW;
+				break;
+			}
+			if (n_prev + b.n_indel >= p.k) {
+				if (is_repeat(prev, (int)n_prev, lps) || n_prev + b.n_indel >= p.insertion_cap) {
+					drop_prev_insertion(n_prev);
+					reseed_after_skip();
+					skipped_repeat = true;
+				} else {
+					for (u32 w = 0; w < b.n_indel; w++) {
+						for (u32 q = n_prev; q > 0; q--) {
+							prev[q] = prev[q - 1];
+						}
+						prev[0] = rc_char(b.indel[w]);
+						n_prev++;
+						if (is_repeat(prev, (int)n_prev, lps)) {
+							drop_prev_insertion(n_prev - w);
+							reseed_after_skip();
+							skipped_repeat = true;
+						}
+					}
+				}
+			}
+			if (!skipped_repeat) {
+				make_insertion(t_node, t_seq_i, b.indel, b.n_indel, b.num_support);
+				changelast(hs, draft_char, b.indel[0]);
+			}
+			break;
+		}
+		case 3:
+			make_deletion(t_node, t_seq_i, b.n_indel, b.num_support);
+			changelast(hs, draft_char, get_character(t_seq_i, nget(t_node)));
+			break;
+		case 0:
+			if (p.mask) {
+				u8 lc = (draft_char >= 'A' && draft_char <= 'Z') ? (u8)(draft_char + 32) : draft_char;
+				if (t_nd.type == 0) {
+					set_seq(t_seq_i, lc);
+				} else if (t_nd.type == 1) {
+					t_nd.c = lc;
+					nset(t_node, t_nd);
+					rope_touched = true;
+				}
+				changelast(hs, draft_char, lc);
+			}
+			break;
+		default:
+			break;
+		}
+	}
+
+	// substitution candidates for a draft base (ntedit.cpp:180-186, polish mode)
+	NTE_HD static u32
+	candidate_bases(u8 draft_char, u8* out)
+	{
+		const char* s;
+		switch (draft_char) {
+		case 'A':
+			s = "TCG";
+			break;
+		case 'T':
+			s = "ACG";
+			break;
+		case 'C':
+			s = "ATG";
+			break;
+		case 'G':
+			s = "ATC";
+			break;
+		case 'R':
+			s = "TC";
+			break;
+		case 'Y':
+			s = "AG";
+			break;
+		case 'S':
+			s = "AT";
+			break;
+		case 'W':
+			s = "CG";
+			break;
+		case 'K':
+			s = "AC";
+			break;
+		case 'M':
+			s = "TG";
+			break;
+		case 'B':
+			s = "A";
+			break;
+		case 'D':
+			s = "C";
+			break;
+		case 'H':
+			s = "G";
+			break;
+		case 'V':
+			s = "T";
+			break;
+		case 'N':
+			s = "ATCG";
+			break;
+		default:
+			s = "";
+		}
+		u32 n = 0;
+		while (s[n]) {
+			out[n] = (u8)s[n];
+			n++;
+		}
+		return n;
+	}
+
+	// The state is "clean" when everything the machine will do from here on is
+	// a function of the un-edited draft: both cursors sit in the open-ended last
+	// position node, the window is k contiguous draft bases, no substituted
+	// base is still inside it.
+	NTE_HD bool
+	is_clean() const
+	{
+		if (h_node != t_node) {
+			return false;
+		}
+		Node n = nget(t_node);
+		if (n.type != 0 || n.e_pos != e.len - 1) {
+			return false;
+		}
+		if (t_node + 1 < nsize && nget(t_node + 1).type != -1) {
+			return false;
+		}
+		if (t_seq_i != h_seq_i + p.k - 1 || h_seq_i < n.s_pos) {
+			return false;
+		}
+		// indels keep the state dirty until both cursors have moved into the
+		// open node behind them, which the node tests above detect
+		return (int64_t)h_seq_i > last_sub_pos;
+	}
+
+	// steps 2-5 + makeEdit for the k-mer currently under the cursors
+	NTE_HD void
+	process_missing(u8 char_in_at_t)
+	{
+		HashState ts = hs;
+		u32 th = h_seq_i, tt = t_seq_i, thn = h_node, ttn = t_node;
+		u8 draft_char = char_in_at_t;
+		if (draft_char >= 'a' && draft_char <= 'z') {
+			draft_char -= 32;
+		}
+		u8 char_out = 0, char_in = 0;
+
+		// step 2: confirm on the k/j subset (ntedit.cpp:1826-1858)
+		u32 check_missing = 0;
+		bool do_not_fix = false;
+		for (u32 k = 0; k < p.k && th < e.len; k++) {
+			if (roll(th, tt, thn, ttn, char_out, char_in)) {
+				roll_hash(ts, char_out, char_in);
+				if (char_code(char_in) == CODE_BAD) {
+					do_not_fix = true;
+					break;
+				}
+				if (k % p.jump == 0 && !in_bloom(ts)) {
+					check_missing++;
+				}
+			} else {
+				do_not_fix = true;
+				break;
+			}
+		}
+		if (do_not_fix || check_missing < p.thr_missing) {
+			return;
+		}
+
+		u32 num_deletions = 1;
+		Best b;
+		b.edit_type = 0;
+		b.n_indel = 0;
+		b.sub_base = 0; // (U2) the reference leaves these uninitialised
+		b.num_support = 0;
+		b.altbase1 = b.altbase2 = b.altbase3 = 0;
+		b.altsupp1 = b.altsupp2 = b.altsupp3 = 0;
+
+		u8 cand[4];
+		u32 n_cand = candidate_bases(draft_char, cand);
+		Node t_nd = nget(t_node);
+		for (u32 ci = 0; ci < n_cand; ci++) {
+			u8 sub_base = cand[ci];
+			ts = hs;
+			changelast(ts, draft_char, sub_base);
+			if (!(present_solid(ts) || p.mode == 2)) {
+				continue;
+			}
+			th = h_seq_i;
+			tt = t_seq_i;
+			thn = h_node;
+			ttn = t_node;
+			// temporarily substitute (ntedit.cpp:1936-1940)
+			if (t_nd.type == 0) {
+				tmp_on = true;
+				tmp_pos = t_seq_i;
+				tmp_chr = sub_base;
+			} else if (t_nd.type == 1) {
+				Node m = t_nd;
+				m.c = sub_base;
+				nset(t_node, m);
+			}
+			u32 check_present = 0;
+			for (u32 k = 0; k < p.k && th < e.len && tt < e.len; k++) {
+				if (roll(th, tt, thn, ttn, char_out, char_in)) {
+					roll_hash(ts, char_out, char_in);
+					if (k % p.jump == 0 && present_solid(ts)) {
+						check_present++;
+					}
+				} else {
+					break;
+				}
+			}
+			// revert -- with the UPPER-cased draft base (ntedit.cpp:1975-1981)
+			if (t_nd.type == 0) {
+				tmp_on = false;
+				set_seq(t_seq_i, draft_char);
+			} else if (t_nd.type == 1) {
+				Node m = t_nd;
+				m.c = draft_char;
+				nset(t_node, m);
+				t_nd = m;
+				rope_touched = true;
+			}
+
+			if (check_present >= p.thr_edit) {
+				if (check_present >= b.num_support) {
+					if (b.altsupp2) {
+						b.altbase3 = b.altbase2;
+						b.altsupp3 = b.altsupp2;
+					}
+					if (b.altsupp1) {
+						b.altbase2 = b.altbase1;
+						b.altsupp2 = b.altsupp1;
+					}
+					if (b.num_support) {
+						b.altsupp1 = b.num_support;
+						b.altbase1 = b.sub_base;
+					}
+					b.edit_type = 1;
+					b.sub_base = sub_base;
+					b.num_support = check_present;
+				} else {
+					if (!b.altsupp1) {
+						b.altbase1 = sub_base;
+						b.altsupp1 = check_present;
+					} else if (!b.altsupp2) {
+						if (check_present < b.altsupp1) {
+							b.altbase2 = sub_base;
+							b.altsupp2 = check_present;
+						} else {
+							b.altbase2 = b.altbase1;
+							b.altsupp2 = b.altsupp1;
+							b.altbase1 = sub_base;
+							b.altsupp1 = check_present;
+						}
+					} else if (!b.altsupp3) {
+						if (check_present < b.altsupp2) {
+							b.altbase3 = sub_base;
+							b.altsupp3 = check_present;
+						} else if (check_present < b.altsupp1) {
+							b.altbase3 = b.altbase2;
+							b.altsupp3 = b.altsupp2;
+							b.altbase2 = sub_base;
+							b.altsupp2 = check_present;
+						} else {
+							b.altbase3 = b.altbase2;
+							b.altsupp3 = b.altsupp2;
+							b.altbase2 = b.altbase1;
+							b.altsupp2 = b.altsupp1;
+							b.altbase1 = sub_base;
+							b.altsupp1 = check_present;
+						}
+					}
+				}
+				if (p.mode == 0 || p.mode == 1) {
+					continue;
+				}
+			}
+			if (p.mode == 2 || b.edit_type != 1) {
+				if (try_indels(draft_char, sub_base, num_deletions, b)) {
+					if (p.mode == 0 || p.mode == 1) {
+						break;
+					}
+				}
+			}
+		}
+		make_edit(draft_char, b);
+	}
+
+	// run one event that starts (clean) with its k-mer head at local position start
+	NTE_HD void
+	run(u32 start, u32& cover_end)
+	{
+		h_seq_i = start;
+		t_seq_i = start + p.k - 1;
+		h_node = t_node = 0;
+		nbase = 0;
+		nsize = 0;
+		rope_touched = false;
+		n_ov = 0;
+		tmp_on = false;
+		tmp_pos = 0;
+		tmp_chr = 0;
+		last_sub_pos = -1;
+		first_chunk = cur_chunk = NONE32;
+		fill = 0;
+		flags = 0;
+		cover_end = start;
+
+		Node root;
+		root.type = 0;
+		root.s_pos = 0;
+		root.e_pos = e.len - 1;
+		root.c = 0;
+		root.support = 0;
+		nput(0, root);
+
+		// seed hash of the k-mer at start (ntedit.cpp:1778; all bases accepted)
+		hs.fh = 0;
+		hs.rh = 0;
+		for (u32 i = 0; i < p.k; i++) {
+			u8 code = char_code(e.seq[start + i]);
+			hs.fh = srol1(hs.fh) ^ e.tab[TAB_F + code];
+		}
+		for (u32 i = p.k; i > 0; i--) {
+			u8 code = char_code(e.seq[start + i - 1]);
+			hs.rh = srol1(hs.rh) ^ e.tab[TAB_R + code];
+		}
+		u8 char_in = e.seq[t_seq_i];
+		u8 char_out = 0;
+
+		bool first = true;
+		while (true) {
+			if ((u64)h_seq_i + p.k - 1 >= e.len) {
+				flags |= EV_TERMINAL;
+				cover_end = e.len;
+				break;
+			}
+			if (flags & EV_OVERFLOW) {
+				cover_end = e.len;
+				break;
+			}
+			bool missing;
+			if (is_clean()) {
+				u64 g = e.gbase + h_seq_i;
+				if (!first && (!bit_absent(e.bitmap, g) || is_event_start(e.bitmap, g, p.start_grid))) {
+					cover_end = h_seq_i;
+					break;
+				}
+				missing = true; // clean state: the screening bitmap already answered
+			} else {
+				missing = !in_bloom(hs);
+			}
+			first = false;
+			if (missing) {
+				process_missing(char_in);
+			}
+			// advance; skip over k-mers containing a non-accepted base (ntedit.cpp:2119-2138)
+			bool ended = false;
+			int64_t target = -1;
+			do {
+				if (roll(h_seq_i, t_seq_i, h_node, t_node, char_out, char_in)) {
+					if (char_code(char_in) == CODE_BAD) {
+						target = (int64_t)t_seq_i + (int64_t)p.k;
+					}
+					roll_hash(hs, char_out, char_in);
+				} else {
+					ended = true;
+					break;
+				}
+			} while (target >= 0 && (int64_t)t_seq_i != target);
+			if (ended) {
+				flags |= EV_TERMINAL;
+				cover_end = e.len;
+				break;
+			}
+			housekeeping();
+		}
+
+		// stream out what is left of the rope (only if an indel touched it)
+		if (rope_touched) {
+			for (u32 i = nbase; i < nsize; i++) {
+				Node n = nget(i);
+				emit_node(n);
+				if (n.type == -1) {
+					break;
+				}
+			}
+		}
+	}
+
+	// seal the chunk chain; returns the first chunk (NONE32 if nothing was emitted)
+	NTE_HD u32
+	finish(u32 start, u32 cover_end)
+	{
+		if (flags & EV_OVERFLOW) {
+			return NONE32;
+		}
+		if (cur_chunk == NONE32) {
+			return NONE32;
+		}
+		Item link;
+		link.w[0] = NONE32;
+		link.w[1] = fill;
+		link.w[2] = link.w[3] = 0;
+		e.arena[(u64)cur_chunk * CHUNK_ITEMS] = link;
+		Item hdr;
+		hdr.w[0] = e.contig;
+		hdr.w[1] = start;
+		hdr.w[2] = cover_end;
+		hdr.w[3] = flags;
+		e.arena[(u64)first_chunk * CHUNK_ITEMS + 1] = hdr;
+		return first_chunk;
+	}
+};
+
+} // namespace nte

@@ -1,0 +1,146 @@
+#include "params.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace nte_host {
+
+void
+params_default(ntedit_hip_params* p)
+{
+	// ntedit.cpp:99-133
+	memset(p, 0, sizeof(*p));
+	p->min_contig_len = 100;
+	p->max_insertions = 5;
+	p->max_deletions = 5;
+	p->edit_threshold = 9.0f;
+	p->missing_threshold = 5.0f;
+	p->edit_ratio = 0.5f;
+	p->missing_ratio = 0.5f;
+	p->use_ratio = 0;
+	p->jump = 3;
+	p->mode = 0;
+	p->snv = 0;
+	p->mask = 0;
+	p->min_threshold = 1;
+	p->max_threshold = 255;
+}
+
+static void
+append(char* warn, size_t cap, const char* msg)
+{
+	if (!warn || !cap) {
+		return;
+	}
+	size_t l = strlen(warn);
+	if (l + 1 < cap) {
+		snprintf(warn + l, cap - l, "%s", msg);
+	}
+}
+
+void
+params_clamp(ntedit_hip_params* p, char* warn, size_t cap)
+{
+	if (warn && cap) {
+		warn[0] = 0;
+	}
+	// ntedit.cpp:2411-2413
+	if (p->snv) {
+		p->max_insertions = 0;
+		p->max_deletions = 0;
+	}
+	// ntedit.cpp:2467-2475: the x/y range test is a conjunction of
+	// contradictory terms and can never fire -- x and y are used as given.
+	// ntedit.cpp:2478-2483
+	if ((p->max_insertions == 0 && p->max_deletions > 0) ||
+	    (p->max_insertions == 1 && p->max_deletions > 1)) {
+		append(
+		    warn,
+		    cap,
+		    "ntEdit v2.1.1: warning: i and d parameter combination is not possible; d was set to the "
+		    "value of i.\n");
+		p->max_deletions = p->max_insertions;
+	}
+	// ntedit.cpp:2485-2493 (the reference prints these without a newline)
+	if (p->max_insertions > 5) {
+		append(warn, cap, "ntEdit v2.1.1: warning: i parameter too high, adjusting to maximum -i 5");
+		p->max_insertions = 5;
+	}
+	if (p->max_deletions > 10) {
+		append(warn, cap, "ntEdit v2.1.1: warning: d parameter too high, adjusting to maximum -d 10");
+		p->max_deletions = 10;
+	}
+}
+
+template<typename F>
+static uint32_t
+first_count(uint32_t k, F ok)
+{
+	for (uint32_t c = 0; c <= k + 2; c++) {
+		if (ok(c)) {
+			return c;
+		}
+	}
+	return 0xFFFFFFFFu;
+}
+
+int
+make_dev_params(
+    const ntedit_hip_params& hp,
+    uint32_t k,
+    uint32_t hash_num,
+    bool secbf,
+    nte::DevParams* out)
+{
+	static const uint32_t num_tries[6] = { 0, 1, 5, 21, 85, 341 }; // ntedit.cpp:172
+	if (k < 12 || k > 200 || hash_num == 0 || hash_num > nte::MAX_HASHES || hp.jump == 0 ||
+	    hp.max_insertions > 5 || hp.max_deletions > 10 || hp.mode < 0 || hp.mode > 2) {
+		return NTEDIT_E_ARG;
+	}
+	if (hp.snv) {
+		return NTEDIT_E_UNSUPPORTED;
+	}
+	nte::DevParams d;
+	memset(&d, 0, sizeof d);
+	d.k = k;
+	d.h = hash_num;
+	d.jump = hp.jump;
+	d.ins_tries = num_tries[hp.max_insertions];
+	d.max_deletions = hp.max_deletions;
+	d.mode = (uint32_t)hp.mode;
+	d.mask = hp.mask ? 1 : 0;
+	d.secbf = secbf ? 1 : 0;
+	// ntedit.cpp:2450-2451 (-c is parsed, then overwritten by k*1.5)
+	d.insertion_cap = (uint32_t)((float)k * 1.5f);
+	const float fk = (float)k;
+	const bool ur = hp.use_ratio != 0;
+	const float x = hp.missing_threshold, y = hp.edit_threshold;
+	const float X = hp.missing_ratio, Y = hp.edit_ratio;
+	const uint32_t jump = hp.jump;
+	d.thr_missing = first_count(k, [&](uint32_t c) {
+		return (!ur && (float)c >= (fk / x)) || (ur && (float)c >= ((fk / jump) * X));
+	});
+	d.thr_edit = first_count(k, [&](uint32_t c) {
+		return (!ur && (float)c >= (fk / y)) || (ur && (float)c >= ((fk / jump)) * Y);
+	});
+	d.thr_edit_del = first_count(k, [&](uint32_t c) {
+		return (!ur && (float)c >= (fk / y)) || (ur && (float)c >= (1 + (fk / jump)) * Y);
+	});
+	uint32_t g = hp.start_grid ? hp.start_grid : 32;
+	if (g & (g - 1)) {
+		return NTEDIT_E_ARG;
+	}
+	d.start_grid = g;
+	uint32_t w = hp.node_window ? hp.node_window : 6 * k + 96;
+	if (w < 4 * k + 64) {
+		w = 4 * k + 64;
+	}
+	d.node_window = w;
+	for (uint32_t i = 0; i < nte::MAX_HASHES; i++) {
+		d.mul[i] = (uint64_t)i ^ ((uint64_t)k * nte::MULTISEED);
+	}
+	*out = d;
+	return 0;
+}
+
+} // namespace nte_host

@@ -1,0 +1,42 @@
+// render.h -- host side of the hot path's output: applies the edit records
+// produced by the event machine to the draft and writes _edited.fa and
+// _changes.tsv exactly as the reference's writeEditsToFile does
+// (ntedit.cpp:925-1213, headers 2175-2188).
+#pragma once
+#include "../csrc/nte_common.h"
+
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+namespace nte_host {
+
+struct RenderStats
+{
+	uint64_t events_applied = 0;
+	uint64_t substitutions = 0;
+	uint64_t insertions = 0;
+	uint64_t deletions = 0;
+};
+
+// arena:    host copy of the chunk arena
+// ev_first: first chunk of every event that produced output, ordered by
+//           global start position (contig order, then position)
+// fa / tsv: may be nullptr (that stream is skipped)
+int render_batch(
+    const nte::Item* arena,
+    size_t arena_items,
+    const uint32_t* ev_first,
+    size_t n_events,
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    FILE* fa,
+    FILE* tsv,
+    RenderStats* stats);
+
+void write_tsv_header(FILE* tsv, uint32_t k, uint32_t jump, bool counting);
+
+} // namespace nte_host

@@ -1,0 +1,241 @@
+"""Shared helpers for the test-suite: oracle / hostsim loaders, FASTA + .bf IO,
+synthetic genome generators.  Test infrastructure only."""
+import ctypes
+import gzip
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_BUILD = os.path.join(ORACLE_DIR, "_build")
+HOSTSIM_DIR = os.path.join(ROOT, "tests", "hostsim")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+class HipParams(ctypes.Structure):
+    _fields_ = [
+        ("min_contig_len", ctypes.c_uint32),
+        ("max_insertions", ctypes.c_uint32),
+        ("max_deletions", ctypes.c_uint32),
+        ("edit_threshold", ctypes.c_float),
+        ("missing_threshold", ctypes.c_float),
+        ("edit_ratio", ctypes.c_float),
+        ("missing_ratio", ctypes.c_float),
+        ("use_ratio", ctypes.c_int32),
+        ("jump", ctypes.c_uint32),
+        ("mode", ctypes.c_int32),
+        ("snv", ctypes.c_int32),
+        ("mask", ctypes.c_int32),
+        ("min_threshold", ctypes.c_uint32),
+        ("max_threshold", ctypes.c_uint32),
+        ("start_grid", ctypes.c_uint32),
+        ("node_window", ctypes.c_uint32),
+    ]
+
+
+def default_params(**kw):
+    p = HipParams(100, 5, 5, 9.0, 5.0, 0.5, 0.5, 0, 3, 0, 0, 0, 1, 255, 0, 0)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+    return ORACLE_BUILD
+
+
+def build_hostsim():
+    subprocess.run(["make", "-s", "-C", HOSTSIM_DIR], check=True)
+    return os.path.join(HOSTSIM_DIR, "_build", "libhostsim.so")
+
+
+_oracle = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        build_oracle()
+        lib = ctypes.CDLL(os.path.join(ORACLE_BUILD, "libntedit_oracle.so"))
+        lib.ora_srol.restype = ctypes.c_uint64
+        lib.ora_srol.argtypes = [ctypes.c_uint64]
+        lib.ora_sror.restype = ctypes.c_uint64
+        lib.ora_sror.argtypes = [ctypes.c_uint64]
+        lib.ora_srol_n.restype = ctypes.c_uint64
+        lib.ora_srol_n.argtypes = [ctypes.c_uint64, ctypes.c_uint]
+        lib.ora_base_forward_hash.restype = ctypes.c_uint64
+        lib.ora_base_forward_hash.argtypes = [ctypes.c_char_p, ctypes.c_uint]
+        lib.ora_base_reverse_hash.restype = ctypes.c_uint64
+        lib.ora_base_reverse_hash.argtypes = [ctypes.c_char_p, ctypes.c_uint]
+        lib.ora_next_forward_hash.restype = ctypes.c_uint64
+        lib.ora_next_forward_hash.argtypes = [ctypes.c_uint64, ctypes.c_uint, ctypes.c_ubyte, ctypes.c_ubyte]
+        lib.ora_next_reverse_hash.restype = ctypes.c_uint64
+        lib.ora_next_reverse_hash.argtypes = [ctypes.c_uint64, ctypes.c_uint, ctypes.c_ubyte, ctypes.c_ubyte]
+        _oracle = lib
+    return _oracle
+
+
+_hostsim = None
+
+
+def hostsim_lib():
+    global _hostsim
+    if _hostsim is None:
+        _hostsim = ctypes.CDLL(build_hostsim())
+    return _hostsim
+
+
+def read_fasta(path):
+    """kseq-like: returns [(header_text, sequence_bytes)]; header = name [+ ' ' + comment]."""
+    op = gzip.open if path.endswith(".gz") else open
+    recs = []
+    name, chunks = None, []
+    with op(path, "rb") as f:
+        for line in f:
+            line = line.rstrip(b"\r\n")
+            if line.startswith(b">"):
+                if name is not None:
+                    recs.append((name, b"".join(chunks)))
+                h = line[1:]
+                parts = h.split(None, 1)
+                nm = parts[0] if parts else b""
+                rest = h[len(nm) + 1:] if len(h) > len(nm) else b""
+                name = nm + (b" " + rest if rest else b"")
+                chunks = []
+            elif name is not None:
+                chunks.append(line)
+    if name is not None:
+        recs.append((name, b"".join(chunks)))
+    return recs
+
+
+def write_fasta(path, recs, width=0):
+    with open(path, "wb") as f:
+        for name, seq in recs:
+            f.write(b">" + name + b"\n")
+            if width:
+                for i in range(0, len(seq), width):
+                    f.write(seq[i:i + width] + b"\n")
+            else:
+                f.write(seq + b"\n")
+
+
+def load_bf(path):
+    """returns dict(k, hash_num, bytes, counting, data=np.uint8 array)"""
+    with open(path, "rb") as f:
+        first = f.readline()
+        assert first.startswith(b"[BTL"), first
+        meta = {"counting": b"Counting" in first}
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError("no [HeaderEnd]")
+            if line.startswith(b"[HeaderEnd]"):
+                break
+            if b"=" in line:
+                key, val = [x.strip() for x in line.split(b"=", 1)]
+                meta[key.decode()] = val.decode().strip('"')
+        data = np.frombuffer(f.read(), dtype=np.uint8)
+    meta["k"] = int(meta["k"])
+    meta["hash_num"] = int(meta["hash_num"])
+    meta["bytes"] = int(meta["bytes"])
+    assert data.size == meta["bytes"], (data.size, meta["bytes"])
+    meta["data"] = data
+    return meta
+
+
+def pack_batch(recs, min_len=0):
+    """Batch layout of include/ntedit_hip.h: contigs separated by '\\n'."""
+    names, offs, lens, parts = [], [], [], []
+    pos = 0
+    for name, seq in recs:
+        if len(seq) < min_len:
+            continue
+        names.append(name)
+        offs.append(pos)
+        lens.append(len(seq))
+        parts.append(seq)
+        parts.append(b"\n")
+        pos += len(seq) + 1
+    blob = b"".join(parts)
+    return blob, np.array(offs, dtype=np.uint64), np.array(lens, dtype=np.uint32), names
+
+
+def run_hostsim(recs, bf, params, out_prefix, rep=None):
+    lib = hostsim_lib()
+    blob, offs, lens, names = pack_batch(recs, params.min_contig_len)
+    n = len(names)
+    name_arr = (ctypes.c_char_p * max(n, 1))(*names)
+    nev = ctypes.c_uint64(0)
+    nap = ctypes.c_uint64(0)
+    rc = lib.hostsim_polish(
+        ctypes.c_char_p(blob), ctypes.c_uint64(len(blob)),
+        offs.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p),
+        name_arr, ctypes.c_uint32(n),
+        bf["data"].ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bf["bytes"]),
+        ctypes.c_uint32(bf["hash_num"]), ctypes.c_uint32(bf["k"]),
+        rep["data"].ctypes.data_as(ctypes.c_void_p) if rep else None,
+        ctypes.c_uint64(rep["bytes"] if rep else 0),
+        ctypes.c_uint32(rep["hash_num"] if rep else 0),
+        ctypes.byref(params),
+        (out_prefix + "_edited.fa").encode(), (out_prefix + "_changes.tsv").encode(),
+        ctypes.byref(nev), ctypes.byref(nap))
+    return rc, nev.value, nap.value
+
+
+def oracle_args(params):
+    a = ["-z", str(params.min_contig_len), "-i", str(params.max_insertions), "-d", str(params.max_deletions),
+         "-j", str(params.jump), "-m", str(params.mode), "-a", str(params.mask)]
+    if params.use_ratio:
+        a += ["-X", repr(float(params.missing_ratio)), "-Y", repr(float(params.edit_ratio))]
+    else:
+        a += ["-x", repr(float(params.missing_threshold)), "-y", repr(float(params.edit_threshold))]
+    return a
+
+
+def run_oracle(draft_path, bf_path, params, out_prefix, rep_path=None):
+    build_oracle()
+    cmd = [os.path.join(ORACLE_BUILD, "ntedit_oracle"), "-f", draft_path, "-r", bf_path, "-b", out_prefix]
+    if rep_path:
+        cmd += ["-e", rep_path]
+    cmd += oracle_args(params)
+    subprocess.run(cmd, check=True)
+
+
+def mkbf(fasta_paths, out, k=25, hashes=3, nbytes=1 << 20):
+    build_oracle()
+    subprocess.run([os.path.join(ORACLE_BUILD, "mkbf"), "-k", str(k), "-g", str(hashes), "-s", str(nbytes),
+                    "-o", out] + list(fasta_paths), check=True)
+
+
+# ---------------------------------------------------------------- synthetic data
+def random_genome(rng, n):
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].tobytes()
+
+
+def mutate(rng, seq, p_sub=1e-3, p_ins=1e-4, p_del=1e-4, max_indel=5):
+    """truth -> draft with substitutions, insertions and deletions"""
+    out = bytearray()
+    i = 0
+    n = len(seq)
+    acgt = b"ACGT"
+    while i < n:
+        r = rng.random()
+        if r < p_sub:
+            c = seq[i]
+            choices = [x for x in acgt if x != c]
+            out.append(choices[int(rng.integers(0, 3))])
+            i += 1
+        elif r < p_sub + p_ins:
+            l = int(min(max_indel, rng.geometric(0.6)))
+            for _ in range(l):
+                out.append(acgt[int(rng.integers(0, 4))])
+        elif r < p_sub + p_ins + p_del:
+            l = int(min(max_indel, rng.geometric(0.6)))
+            i += l
+        else:
+            out.append(seq[i])
+            i += 1
+    return bytes(out)

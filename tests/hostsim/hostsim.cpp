@@ -1,0 +1,196 @@
+// hostsim.cpp -- TEST-ONLY host build of the device-side control logic.
+//
+// The event machine (ntedit_amd/csrc/nte_machine.h) and the hashing / filter
+// arithmetic (nte_common.h) are written as host+device code.  This file
+// compiles them with the host compiler and drives them with a plain loop
+// (screen -> event starts -> one machine run per event -> render), so that
+// the CPU test tier can check the product's control logic and host renderer
+// against the oracle without a GPU.  It is never linked into the shipped
+// library and is not a fallback: ntedit_amd refuses to run without the HIP
+// extension.
+#include "../../ntedit_amd/csrc/nte_machine.h"
+#include "../../ntedit_amd/host/params.h"
+#include "../../ntedit_amd/host/render.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace nte;
+
+static Filter
+make_filter(const uint8_t* data, uint64_t nbytes, uint32_t hash_num)
+{
+	Filter f;
+	f.data = data;
+	f.bits = nbytes * 8;
+	f.mask = (f.bits & (f.bits - 1)) == 0 ? f.bits - 1 : 0;
+	f.hash_num = hash_num;
+	f.pad = 0;
+	return f;
+}
+
+// same contract as the screening kernel
+static void
+sim_screen(const u8* seq, u64 n, const Filter& f, const DevParams& p, const u64* tab, u64* bitmap)
+{
+	memset(bitmap, 0, ((n + 63) / 64) * 8);
+	HashState hs = { 0, 0 };
+	u64 good = 0;
+	for (u64 i = 0; i < n; i++) {
+		u8 in = char_code(seq[i]);
+		u8 out = i >= p.k ? char_code(seq[i - p.k]) : CODE_BAD;
+		hash_roll(hs, tab, out, in);
+		good = in == CODE_BAD ? 0 : good + 1;
+		if (good >= p.k) {
+			if (!filter_contains(f, p, hs)) {
+				u64 s = i + 1 - p.k;
+				bitmap[s >> 6] |= 1ULL << (s & 63);
+			}
+		}
+	}
+}
+
+extern "C" int
+hostsim_screen(
+    const char* bases,
+    uint64_t n,
+    const uint8_t* bf,
+    uint64_t bf_bytes,
+    uint32_t hash_num,
+    uint32_t k,
+    uint64_t* bitmap)
+{
+	ntedit_hip_params hp;
+	nte_host::params_default(&hp);
+	DevParams p;
+	if (nte_host::make_dev_params(hp, k, hash_num, false, &p)) {
+		return -1;
+	}
+	u64 tab[TAB_WORDS];
+	build_seed_tables(k, tab);
+	Filter f = make_filter(bf, bf_bytes, hash_num);
+	sim_screen((const u8*)bases, n, f, p, tab, bitmap);
+	return 0;
+}
+
+extern "C" int
+hostsim_polish(
+    const char* bases,
+    uint64_t n,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    const uint8_t* bf,
+    uint64_t bf_bytes,
+    uint32_t hash_num,
+    uint32_t k,
+    const uint8_t* rep,
+    uint64_t rep_bytes,
+    uint32_t rep_hash_num,
+    const ntedit_hip_params* hp,
+    const char* fa_path,
+    const char* tsv_path,
+    uint64_t* n_events_out,
+    uint64_t* n_applied_out)
+{
+	DevParams p;
+	int rc = nte_host::make_dev_params(*hp, k, hash_num, rep != nullptr, &p);
+	if (rc) {
+		return rc;
+	}
+	u64 tab[TAB_WORDS];
+	build_seed_tables(k, tab);
+	Filter f = make_filter(bf, bf_bytes, hash_num);
+	Filter fr = make_filter(rep, rep_bytes, rep ? rep_hash_num : 0);
+
+	std::vector<u64> bitmap((n + 63) / 64 + 1);
+	sim_screen((const u8*)bases, n, f, p, tab, bitmap.data());
+
+	// event starts, in position order
+	std::vector<u64> events;
+	for (u64 g = 0; g < n; g++) {
+		if (is_event_start(bitmap.data(), g, p.start_grid)) {
+			events.push_back(g);
+		}
+	}
+	// arena: generous
+	u32 arena_chunks = (u32)(events.size() * 4 + 1024);
+	std::vector<Item> arena((size_t)arena_chunks * CHUNK_ITEMS);
+	u32 arena_next = 0;
+	std::vector<Node> nodes(p.node_window);
+	std::vector<u32> ov_pos(p.node_window);
+	std::vector<u8> ov_chr(p.node_window);
+	std::vector<u32> ev_first;
+	bool overflow = false;
+
+	u32 ci = 0;
+	for (u64 g : events) {
+		while (ci + 1 < n_contigs && offsets[ci + 1] <= g) {
+			ci++;
+		}
+		EventEnv env;
+		env.seq = (const u8*)bases + offsets[ci];
+		env.len = lens[ci];
+		env.contig = ci;
+		env.gbase = offsets[ci];
+		env.bitmap = bitmap.data();
+		env.tab = tab;
+		env.p = &p;
+		env.bloom = f;
+		env.rep = fr;
+		env.nodes = nodes.data();
+		env.ov_pos = ov_pos.data();
+		env.ov_chr = ov_chr.data();
+		env.arena = arena.data();
+		env.arena_next = &arena_next;
+		env.arena_chunks = arena_chunks;
+		Machine m(env);
+		u32 start = (u32)(g - offsets[ci]);
+		u32 cover_end = start;
+		m.run(start, cover_end);
+		if (m.flags & EV_OVERFLOW) {
+			overflow = true;
+		}
+		u32 fc = m.finish(start, cover_end);
+		if (fc != NONE32) {
+			ev_first.push_back(fc);
+		}
+	}
+	if (overflow) {
+		return NTEDIT_E_OVERFLOW;
+	}
+	FILE* fa = fa_path ? fopen(fa_path, "w") : nullptr;
+	FILE* tsv = tsv_path ? fopen(tsv_path, "w") : nullptr;
+	if (tsv) {
+		nte_host::write_tsv_header(tsv, k, hp->jump, false);
+	}
+	nte_host::RenderStats st;
+	rc = nte_host::render_batch(
+	    arena.data(),
+	    arena.size(),
+	    ev_first.data(),
+	    ev_first.size(),
+	    bases,
+	    offsets,
+	    lens,
+	    names,
+	    n_contigs,
+	    fa,
+	    tsv,
+	    &st);
+	if (fa) {
+		fclose(fa);
+	}
+	if (tsv) {
+		fclose(tsv);
+	}
+	if (n_events_out) {
+		*n_events_out = events.size();
+	}
+	if (n_applied_out) {
+		*n_applied_out = st.events_applied;
+	}
+	return rc;
+}

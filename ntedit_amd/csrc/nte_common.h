@@ -284,7 +284,8 @@ enum ItemTag : u32
 enum EventFlags : u32
 {
 	EV_TERMINAL = 1,  // ran to the end of the contig
-	EV_OVERFLOW = 2   // ran out of node window / arena: results invalid
+	EV_OVERFLOW = 2,  // ran out of node window: results invalid (retry with a larger window)
+	EV_ARENA_FULL = 4 // output arena exhausted: results invalid (retry with a larger arena)
 };
 
 struct Item

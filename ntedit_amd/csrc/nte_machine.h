@@ -115,13 +115,13 @@ struct Machine
 	NTE_HD void
 	emit(const Item& it)
 	{
-		if (flags & EV_OVERFLOW) {
+		if (flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
 			return;
 		}
 		if (cur_chunk == NONE32 || fill == CHUNK_ITEMS) {
 			u32 c = NTE_ATOMIC_INC(e.arena_next);
 			if (c >= e.arena_chunks) {
-				flags |= EV_OVERFLOW;
+				flags |= EV_ARENA_FULL;
 				return;
 			}
 			if (cur_chunk == NONE32) {
@@ -408,8 +408,11 @@ struct Machine
 				end++;
 			}
 			u32 n_re = end - tn;
+			while (nsize < tn + n_ins + n_re && !(flags & EV_OVERFLOW)) {
+				nput(nsize, unset_node()); // grow first, then shift in place
+			}
 			for (u32 q = n_re; q > 0; q--) {
-				nput(tn + n_ins + q - 1, nget(tn + q - 1));
+				nset(tn + n_ins + q - 1, nget(tn + q - 1));
 			}
 			for (u32 q = 0; q < n_ins; q++) {
 				cn.c = ins[q];
@@ -1225,7 +1228,7 @@ struct Machine
 				cover_end = e.len;
 				break;
 			}
-			if (flags & EV_OVERFLOW) {
+			if (flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
 				cover_end = e.len;
 				break;
 			}
@@ -1270,10 +1273,10 @@ struct Machine
 		if (rope_touched) {
 			for (u32 i = nbase; i < nsize; i++) {
 				Node n = nget(i);
-				emit_node(n);
 				if (n.type == -1) {
-					break;
+					break; // unset slots behind the rope are spare capacity, not content
 				}
+				emit_node(n);
 			}
 		}
 	}
@@ -1282,7 +1285,7 @@ struct Machine
 	NTE_HD u32
 	finish(u32 start, u32 cover_end)
 	{
-		if (flags & EV_OVERFLOW) {
+		if (flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
 			return NONE32;
 		}
 		if (cur_chunk == NONE32) {

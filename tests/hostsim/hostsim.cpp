@@ -116,7 +116,7 @@ hostsim_polish(
 		}
 	}
 	// arena: generous
-	u32 arena_chunks = (u32)(events.size() * 4 + 1024);
+	u32 arena_chunks = (u32)(events.size() * 4 + n / 8 + 1024);
 	std::vector<Item> arena((size_t)arena_chunks * CHUNK_ITEMS);
 	u32 arena_next = 0;
 	std::vector<Node> nodes(p.node_window);
@@ -150,10 +150,14 @@ hostsim_polish(
 		u32 start = (u32)(g - offsets[ci]);
 		u32 cover_end = start;
 		m.run(start, cover_end);
-		if (m.flags & EV_OVERFLOW) {
+		if (m.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
 			overflow = true;
 		}
 		u32 fc = m.finish(start, cover_end);
+		if (getenv("HOSTSIM_DEBUG")) {
+			if (fc != NONE32) { const Item* c = arena.data() + (size_t)fc*CHUNK_ITEMS; for (u32 i=0;i<c[0].w[1];i++) fprintf(stderr,"   item %u: %08x %u %u %u\n", i, c[i].w[0], c[i].w[1], c[i].w[2], c[i].w[3]); }
+			fprintf(stderr, "event contig %u start %u cover_end %u flags %u first_chunk %d nsize %u nbase %u\n", ci, start, cover_end, m.flags, (int)fc, m.nsize, m.nbase);
+		}
 		if (fc != NONE32) {
 			ev_first.push_back(fc);
 		}

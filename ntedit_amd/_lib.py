@@ -1,0 +1,114 @@
+"""ctypes binding of include/ntedit_hip.h (libntedit_hip.so, built in-tree).
+
+There is deliberately no fallback: if the HIP library is missing or no GPU is
+visible, every compute call raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libntedit_hip.so")
+
+
+class NtEditHipError(RuntimeError):
+    pass
+
+
+class Params(ctypes.Structure):
+    """ntedit_hip_params (the reference's opt:: block, ntedit.cpp:99-133)."""
+    _fields_ = [
+        ("min_contig_len", ctypes.c_uint32),
+        ("max_insertions", ctypes.c_uint32),
+        ("max_deletions", ctypes.c_uint32),
+        ("edit_threshold", ctypes.c_float),
+        ("missing_threshold", ctypes.c_float),
+        ("edit_ratio", ctypes.c_float),
+        ("missing_ratio", ctypes.c_float),
+        ("use_ratio", ctypes.c_int32),
+        ("jump", ctypes.c_uint32),
+        ("mode", ctypes.c_int32),
+        ("snv", ctypes.c_int32),
+        ("mask", ctypes.c_int32),
+        ("min_threshold", ctypes.c_uint32),
+        ("max_threshold", ctypes.c_uint32),
+        ("start_grid", ctypes.c_uint32),
+        ("node_window", ctypes.c_uint32),
+    ]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("bases", ctypes.c_uint64),
+        ("absent_kmers", ctypes.c_uint64),
+        ("events", ctypes.c_uint64),
+        ("events_applied", ctypes.c_uint64),
+        ("substitutions", ctypes.c_uint64),
+        ("insertions", ctypes.c_uint64),
+        ("deletions", ctypes.c_uint64),
+        ("ms_screen", ctypes.c_float),
+        ("ms_extract", ctypes.c_float),
+        ("ms_machine", ctypes.c_float),
+        ("ms_total", ctypes.c_float),
+    ]
+
+
+# every symbol include/ntedit_hip.h declares
+EXPORTS = [
+    "ntedit_hip_params_default", "ntedit_hip_params_clamp", "ntedit_hip_create", "ntedit_hip_destroy",
+    "ntedit_hip_last_error", "ntedit_hip_set_filter", "ntedit_hip_set_filter_device",
+    "ntedit_hip_load_filter_file", "ntedit_hip_filter_info", "ntedit_hip_filter_device_ptr",
+    "ntedit_hip_filter_alloc", "ntedit_hip_filter_insert", "ntedit_hip_filter_download",
+    "ntedit_hip_filter_save_file", "ntedit_hip_set_params", "ntedit_hip_screen", "ntedit_hip_polish_batch",
+    "ntedit_hip_result_free", "ntedit_hip_result_stats", "ntedit_hip_write_outputs",
+    "ntedit_hip_write_tsv_header", "ntedit_hip_last_kernel_ms", "ntedit_hip_gather_bench",
+]
+
+_lib = None
+
+
+def load():
+    """Load libntedit_hip.so; raises NtEditHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NtEditHipError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C ntedit_amd/csrc). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u64, u32, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+    lib.ntedit_hip_params_default.argtypes = [ctypes.POINTER(Params)]
+    lib.ntedit_hip_params_default.restype = None
+    lib.ntedit_hip_params_clamp.argtypes = [ctypes.POINTER(Params), ctypes.c_char_p, ctypes.c_size_t]
+    lib.ntedit_hip_params_clamp.restype = None
+    lib.ntedit_hip_create.argtypes = [ci, ctypes.POINTER(vp)]
+    lib.ntedit_hip_destroy.argtypes = [vp]
+    lib.ntedit_hip_destroy.restype = None
+    lib.ntedit_hip_last_error.argtypes = [vp]
+    lib.ntedit_hip_last_error.restype = ctypes.c_char_p
+    lib.ntedit_hip_set_filter.argtypes = [vp, ci, vp, u64, u32, u32, ci]
+    lib.ntedit_hip_set_filter_device.argtypes = [vp, ci, vp, u64, u32, u32, ci]
+    lib.ntedit_hip_load_filter_file.argtypes = [vp, ci, ctypes.c_char_p]
+    lib.ntedit_hip_filter_info.argtypes = [vp, ci, ctypes.POINTER(u32), ctypes.POINTER(u32),
+                                           ctypes.POINTER(u64), ctypes.POINTER(ci)]
+    lib.ntedit_hip_filter_device_ptr.argtypes = [vp, ci]
+    lib.ntedit_hip_filter_device_ptr.restype = vp
+    lib.ntedit_hip_filter_alloc.argtypes = [vp, ci, u64, u32, u32]
+    lib.ntedit_hip_filter_insert.argtypes = [vp, ci, vp, u64, ci]
+    lib.ntedit_hip_filter_download.argtypes = [vp, ci, vp]
+    lib.ntedit_hip_filter_save_file.argtypes = [vp, ci, ctypes.c_char_p]
+    lib.ntedit_hip_set_params.argtypes = [vp, ctypes.POINTER(Params)]
+    lib.ntedit_hip_screen.argtypes = [vp, vp, u64, ci, vp]
+    lib.ntedit_hip_polish_batch.argtypes = [vp, vp, u64, vp, vp, u32, ci, ctypes.POINTER(vp)]
+    lib.ntedit_hip_result_free.argtypes = [vp]
+    lib.ntedit_hip_result_free.restype = None
+    lib.ntedit_hip_result_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    lib.ntedit_hip_write_outputs.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_char_p), u32,
+                                             ctypes.c_char_p, ctypes.c_char_p, ci]
+    lib.ntedit_hip_write_tsv_header.argtypes = [ctypes.c_char_p, u32, u32, ci]
+    lib.ntedit_hip_last_kernel_ms.argtypes = [vp]
+    lib.ntedit_hip_last_kernel_ms.restype = ctypes.c_float
+    lib.ntedit_hip_gather_bench.argtypes = [vp, u64, u64, ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_float)]
+    _lib = lib
+    return lib

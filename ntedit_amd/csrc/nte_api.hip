@@ -1,0 +1,968 @@
+// nte_api.hip -- implementation of the C ABI in include/ntedit_hip.h.
+// Host side of the library: context / buffer management on one MI355X,
+// kernel launches on the context's HIP stream, HIP-event timing, and the glue
+// to the host renderer.  No CPU compute path exists here: every entry point
+// that needs the GPU fails with NTEDIT_E_DEVICE when there is none.
+#include "nte_kernels.hip"
+
+#include "../../include/ntedit_hip.h"
+#include "../host/bfio.h"
+#include "../host/params.h"
+#include "../host/render.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace nte;
+
+namespace {
+
+struct DevBuf
+{
+	void* p = nullptr;
+	size_t cap = 0;
+};
+
+struct DevFilter
+{
+	u8* data = nullptr;
+	u64 nbytes = 0;
+	u32 hash_num = 0, k = 0;
+	bool counting = false, owned = false, set = false;
+};
+
+} // namespace
+
+struct ntedit_hip_ctx
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	DevFilter filt[2];
+	ntedit_hip_params hp;
+	DevParams dp;
+	bool dp_valid = false;
+	u64* d_tab = nullptr;
+	u32 tab_k = 0;
+	std::string err;
+	float last_ms = 0.f;
+	hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters;
+	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps;
+	DevBuf offs, lens;
+	u32 cu_count = 256;
+};
+
+struct ntedit_hip_result
+{
+	std::vector<Item> arena;
+	std::vector<u32> ev_first;
+	ntedit_hip_stats st;
+	nte_host::RenderStats rst;
+};
+
+namespace {
+
+int
+fail(ntedit_hip_ctx* c, int code, const char* fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (c) {
+		c->err = buf;
+	}
+	return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+	do {                                                                                         \
+		hipError_t e_ = (expr);                                                                  \
+		if (e_ != hipSuccess) {                                                                  \
+			return fail((ctx), NTEDIT_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));         \
+		}                                                                                        \
+	} while (0)
+
+int
+ensure(ntedit_hip_ctx* c, DevBuf& b, size_t bytes)
+{
+	if (bytes <= b.cap) {
+		return 0;
+	}
+	if (b.p) {
+		HIP_TRY(c, hipFree(b.p));
+		b.p = nullptr;
+		b.cap = 0;
+	}
+	size_t want = bytes + bytes / 8 + 256;
+	HIP_TRY(c, hipMalloc(&b.p, want));
+	b.cap = want;
+	return 0;
+}
+
+void
+release(DevBuf& b)
+{
+	if (b.p) {
+		(void)hipFree(b.p);
+	}
+	b.p = nullptr;
+	b.cap = 0;
+}
+
+Filter
+dev_filter(const DevFilter& f)
+{
+	Filter r;
+	r.data = f.data;
+	r.bits = f.nbytes * 8;
+	r.mask = (r.bits && (r.bits & (r.bits - 1)) == 0) ? r.bits - 1 : 0;
+	r.hash_num = f.hash_num;
+	r.pad = 0;
+	return r;
+}
+
+int
+refresh_params(ntedit_hip_ctx* c)
+{
+	const DevFilter& f = c->filt[0];
+	if (!f.set) {
+		return fail(c, NTEDIT_E_NOFILTER, "primary Bloom filter not set");
+	}
+	if (f.counting) {
+		return fail(c, NTEDIT_E_UNSUPPORTED, "counting Bloom filters are not supported on the HIP path yet");
+	}
+	const DevFilter& r = c->filt[1];
+	if (r.set) {
+		if (r.counting) {
+			return fail(c, NTEDIT_E_UNSUPPORTED, "counting secondary Bloom filter not supported");
+		}
+		if (r.k != f.k) {
+			// ntedit.cpp:2581-2585
+			return fail(
+			    c,
+			    NTEDIT_E_ARG,
+			    "secondary Bloom filter k size (%u) is different than main Bloom filter k size (%u)",
+			    r.k,
+			    f.k);
+		}
+	}
+	int rc = nte_host::make_dev_params(c->hp, f.k, f.hash_num, r.set, &c->dp);
+	if (rc) {
+		return fail(c, rc, "unsupported parameter combination (k=%u h=%u)", f.k, f.hash_num);
+	}
+	if (!c->d_tab) {
+		HIP_TRY(c, hipMalloc((void**)&c->d_tab, TAB_WORDS * sizeof(u64)));
+	}
+	if (c->tab_k != f.k) {
+		u64 tab[TAB_WORDS];
+		build_seed_tables(f.k, tab);
+		HIP_TRY(c, hipMemcpy(c->d_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+		c->tab_k = f.k;
+	}
+	c->dp_valid = true;
+	return 0;
+}
+
+template<bool INSERT>
+int
+launch_screen(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words)
+{
+	const u64 blocks = (n + SCREEN_TILE - 1) / SCREEN_TILE;
+	if (blocks == 0) {
+		return 0;
+	}
+	if (blocks > 0x7FFFFFFFull) {
+		return fail(c, NTEDIT_E_ARG, "batch too large");
+	}
+	dim3 grid((unsigned)blocks), block(SCREEN_TPB);
+	const bool pow2 = f.mask != 0;
+#define NTE_LAUNCH(H)                                                                            \
+	do {                                                                                         \
+		if (pow2) {                                                                              \
+			hipLaunchKernelGGL(                                                                  \
+			    (k_screen<H, true, INSERT>), grid, block, 0, c->stream, d_seq, n, f, c->dp,      \
+			    c->d_tab, d_bitmap, n_words);                                                    \
+		} else {                                                                                 \
+			hipLaunchKernelGGL(                                                                  \
+			    (k_screen<H, false, INSERT>), grid, block, 0, c->stream, d_seq, n, f, c->dp,     \
+			    c->d_tab, d_bitmap, n_words);                                                    \
+		}                                                                                        \
+	} while (0)
+	switch (f.hash_num) {
+	case 1:
+		NTE_LAUNCH(1);
+		break;
+	case 2:
+		NTE_LAUNCH(2);
+		break;
+	case 3:
+		NTE_LAUNCH(3);
+		break;
+	case 4:
+		NTE_LAUNCH(4);
+		break;
+	case 5:
+		NTE_LAUNCH(5);
+		break;
+	default:
+		NTE_LAUNCH(0);
+		break;
+	}
+#undef NTE_LAUNCH
+	HIP_TRY(c, hipGetLastError());
+	return 0;
+}
+
+// copies (or adopts) the batch into HBM; returns the device pointer
+int
+stage_bases(ntedit_hip_ctx* c, const char* bases, u64 n, int on_device, const u8** out)
+{
+	if (on_device) {
+		if ((uintptr_t)bases & 15) {
+			return fail(c, NTEDIT_E_ARG, "device `bases` must be 16-byte aligned");
+		}
+		*out = (const u8*)bases;
+		return 0;
+	}
+	int rc = ensure(c, c->seq, n + 64);
+	if (rc) {
+		return rc;
+	}
+	HIP_TRY(c, hipMemcpyAsync(c->seq.p, bases, n, hipMemcpyHostToDevice, c->stream));
+	*out = (const u8*)c->seq.p;
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+void
+ntedit_hip_params_default(ntedit_hip_params* p)
+{
+	nte_host::params_default(p);
+}
+
+void
+ntedit_hip_params_clamp(ntedit_hip_params* p, char* warn, size_t cap)
+{
+	nte_host::params_clamp(p, warn, cap);
+}
+
+int
+ntedit_hip_create(int device, ntedit_hip_ctx** out)
+{
+	if (!out) {
+		return NTEDIT_E_ARG;
+	}
+	*out = nullptr;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+		return NTEDIT_E_DEVICE;
+	}
+	if (device < 0 || device >= count) {
+		return NTEDIT_E_ARG;
+	}
+	if (hipSetDevice(device) != hipSuccess) {
+		return NTEDIT_E_DEVICE;
+	}
+	ntedit_hip_ctx* c = new ntedit_hip_ctx();
+	c->device = device;
+	nte_host::params_default(&c->hp);
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+		c->cu_count = (u32)prop.multiProcessorCount;
+	}
+	if (hipStreamCreate(&c->stream) != hipSuccess) {
+		delete c;
+		return NTEDIT_E_DEVICE;
+	}
+	for (auto& e : c->ev) {
+		if (hipEventCreate(&e) != hipSuccess) {
+			delete c;
+			return NTEDIT_E_DEVICE;
+		}
+	}
+	*out = c;
+	return 0;
+}
+
+void
+ntedit_hip_destroy(ntedit_hip_ctx* c)
+{
+	if (!c) {
+		return;
+	}
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for (auto& f : c->filt) {
+		if (f.owned && f.data) {
+			(void)hipFree(f.data);
+		}
+	}
+	DevBuf* bufs[] = { &c->seq,      &c->bitmap,   &c->block_counts, &c->block_offsets, &c->events,
+		               &c->first_chunk, &c->arena, &c->counters,     &c->ws_nodes,      &c->ws_ov_pos,
+		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps,       &c->offs,          &c->lens };
+	for (DevBuf* b : bufs) {
+		release(*b);
+	}
+	if (c->d_tab) {
+		(void)hipFree(c->d_tab);
+	}
+	for (auto& e : c->ev) {
+		if (e) {
+			(void)hipEventDestroy(e);
+		}
+	}
+	if (c->stream) {
+		(void)hipStreamDestroy(c->stream);
+	}
+	delete c;
+}
+
+const char*
+ntedit_hip_last_error(const ntedit_hip_ctx* c)
+{
+	return c ? c->err.c_str() : "no context";
+}
+
+static int
+drop_filter(ntedit_hip_ctx* c, int slot)
+{
+	DevFilter& f = c->filt[slot];
+	if (f.owned && f.data) {
+		HIP_TRY(c, hipFree(f.data));
+	}
+	f = DevFilter();
+	c->dp_valid = false;
+	return 0;
+}
+
+int
+ntedit_hip_set_filter(
+    ntedit_hip_ctx* c,
+    int slot,
+    const uint8_t* bits,
+    uint64_t nbytes,
+    uint32_t hash_num,
+    uint32_t k,
+    int counting)
+{
+	if (!c || slot < 0 || slot > 1 || !bits || nbytes == 0 || (nbytes & 7)) {
+		return fail(c, NTEDIT_E_ARG, "set_filter: bad argument");
+	}
+	HIP_TRY(c, hipSetDevice(c->device));
+	int rc = drop_filter(c, slot);
+	if (rc) {
+		return rc;
+	}
+	DevFilter& f = c->filt[slot];
+	HIP_TRY(c, hipMalloc((void**)&f.data, nbytes));
+	f.owned = true;
+	HIP_TRY(c, hipMemcpy(f.data, bits, nbytes, hipMemcpyHostToDevice));
+	f.nbytes = nbytes;
+	f.hash_num = hash_num;
+	f.k = k;
+	f.counting = counting != 0;
+	f.set = true;
+	return 0;
+}
+
+int
+ntedit_hip_set_filter_device(
+    ntedit_hip_ctx* c,
+    int slot,
+    void* device_bits,
+    uint64_t nbytes,
+    uint32_t hash_num,
+    uint32_t k,
+    int counting)
+{
+	if (!c || slot < 0 || slot > 1 || !device_bits || nbytes == 0 || (nbytes & 7) ||
+	    ((uintptr_t)device_bits & 7)) {
+		return fail(c, NTEDIT_E_ARG, "set_filter_device: bad argument");
+	}
+	HIP_TRY(c, hipSetDevice(c->device));
+	int rc = drop_filter(c, slot);
+	if (rc) {
+		return rc;
+	}
+	DevFilter& f = c->filt[slot];
+	f.data = (u8*)device_bits;
+	f.owned = false;
+	f.nbytes = nbytes;
+	f.hash_num = hash_num;
+	f.k = k;
+	f.counting = counting != 0;
+	f.set = true;
+	return 0;
+}
+
+int
+ntedit_hip_load_filter_file(ntedit_hip_ctx* c, int slot, const char* path)
+{
+	if (!c || slot < 0 || slot > 1 || !path) {
+		return fail(c, NTEDIT_E_ARG, "load_filter_file: bad argument");
+	}
+	nte_host::BfHeader h;
+	FILE* f = nte_host::bf_open(path, &h);
+	if (!f) {
+		return fail(c, NTEDIT_E_IO, "`%s': not a readable btllib Bloom filter file", path);
+	}
+	HIP_TRY(c, hipSetDevice(c->device));
+	int rc = drop_filter(c, slot);
+	if (rc) {
+		fclose(f);
+		return rc;
+	}
+	DevFilter& d = c->filt[slot];
+	const u64 nbytes = (h.bytes + 7) / 8 * 8;
+	if (hipMalloc((void**)&d.data, nbytes) != hipSuccess) {
+		fclose(f);
+		return fail(c, NTEDIT_E_DEVICE, "hipMalloc(%llu) failed", (unsigned long long)nbytes);
+	}
+	d.owned = true;
+	(void)hipMemset(d.data, 0, nbytes);
+	// stream the array through a pinned bounce buffer
+	const size_t CH = 64u << 20;
+	void* bounce = nullptr;
+	if (hipHostMalloc(&bounce, CH, hipHostMallocDefault) != hipSuccess) {
+		fclose(f);
+		return fail(c, NTEDIT_E_DEVICE, "hipHostMalloc failed");
+	}
+	u64 done = 0;
+	bool ok = true;
+	while (done < h.bytes) {
+		size_t want = (size_t)((h.bytes - done) < CH ? (h.bytes - done) : CH);
+		size_t got = fread(bounce, 1, want, f);
+		if (got != want) {
+			ok = false;
+			break;
+		}
+		if (hipMemcpy(d.data + done, bounce, got, hipMemcpyHostToDevice) != hipSuccess) {
+			ok = false;
+			break;
+		}
+		done += got;
+	}
+	(void)hipHostFree(bounce);
+	fclose(f);
+	if (!ok) {
+		drop_filter(c, slot);
+		return fail(c, NTEDIT_E_IO, "`%s': truncated Bloom filter file", path);
+	}
+	d.nbytes = nbytes;
+	d.hash_num = h.hash_num;
+	d.k = h.k;
+	d.counting = h.counting;
+	d.set = true;
+	return 0;
+}
+
+int
+ntedit_hip_filter_info(
+    const ntedit_hip_ctx* c,
+    int slot,
+    uint32_t* k,
+    uint32_t* hash_num,
+    uint64_t* nbytes,
+    int* counting)
+{
+	if (!c || slot < 0 || slot > 1 || !c->filt[slot].set) {
+		return NTEDIT_E_NOFILTER;
+	}
+	const DevFilter& f = c->filt[slot];
+	if (k) {
+		*k = f.k;
+	}
+	if (hash_num) {
+		*hash_num = f.hash_num;
+	}
+	if (nbytes) {
+		*nbytes = f.nbytes;
+	}
+	if (counting) {
+		*counting = f.counting;
+	}
+	return 0;
+}
+
+void*
+ntedit_hip_filter_device_ptr(const ntedit_hip_ctx* c, int slot)
+{
+	if (!c || slot < 0 || slot > 1 || !c->filt[slot].set) {
+		return nullptr;
+	}
+	return c->filt[slot].data;
+}
+
+int
+ntedit_hip_filter_alloc(ntedit_hip_ctx* c, int slot, uint64_t nbytes, uint32_t hash_num, uint32_t k)
+{
+	if (!c || slot < 0 || slot > 1 || nbytes == 0 || hash_num == 0 || hash_num > MAX_HASHES) {
+		return fail(c, NTEDIT_E_ARG, "filter_alloc: bad argument");
+	}
+	HIP_TRY(c, hipSetDevice(c->device));
+	int rc = drop_filter(c, slot);
+	if (rc) {
+		return rc;
+	}
+	nbytes = (nbytes + 7) / 8 * 8;
+	DevFilter& f = c->filt[slot];
+	HIP_TRY(c, hipMalloc((void**)&f.data, nbytes));
+	f.owned = true;
+	HIP_TRY(c, hipMemset(f.data, 0, nbytes));
+	f.nbytes = nbytes;
+	f.hash_num = hash_num;
+	f.k = k;
+	f.counting = false;
+	f.set = true;
+	return 0;
+}
+
+int
+ntedit_hip_filter_insert(ntedit_hip_ctx* c, int slot, const char* bases, uint64_t n, int on_device)
+{
+	if (!c || slot < 0 || slot > 1 || !c->filt[slot].set || !bases) {
+		return fail(c, NTEDIT_E_ARG, "filter_insert: bad argument");
+	}
+	HIP_TRY(c, hipSetDevice(c->device));
+	const DevFilter& df = c->filt[slot];
+	// insertion only needs k, the multipliers and the seed tables
+	ntedit_hip_params hp;
+	nte_host::params_default(&hp);
+	DevParams saved = c->dp;
+	bool saved_valid = c->dp_valid;
+	int rc = nte_host::make_dev_params(hp, df.k, df.hash_num, false, &c->dp);
+	if (rc) {
+		c->dp = saved;
+		return fail(c, rc, "filter_insert: unsupported k/hash_num");
+	}
+	if (!c->d_tab) {
+		HIP_TRY(c, hipMalloc((void**)&c->d_tab, TAB_WORDS * sizeof(u64)));
+	}
+	if (c->tab_k != df.k) {
+		u64 tab[TAB_WORDS];
+		build_seed_tables(df.k, tab);
+		HIP_TRY(c, hipMemcpy(c->d_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+		c->tab_k = df.k;
+	}
+	const u8* d_seq = nullptr;
+	rc = stage_bases(c, bases, n, on_device, &d_seq);
+	if (rc == 0) {
+		HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+		rc = launch_screen<true>(c, d_seq, n, dev_filter(df), nullptr, 0);
+		HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev[0], c->ev[1]));
+	}
+	c->dp = saved;
+	c->dp_valid = saved_valid;
+	return rc;
+}
+
+int
+ntedit_hip_filter_download(const ntedit_hip_ctx* c, int slot, uint8_t* bits)
+{
+	if (!c || slot < 0 || slot > 1 || !c->filt[slot].set || !bits) {
+		return NTEDIT_E_ARG;
+	}
+	if (hipSetDevice(c->device) != hipSuccess) {
+		return NTEDIT_E_DEVICE;
+	}
+	const DevFilter& f = c->filt[slot];
+	return hipMemcpy(bits, f.data, f.nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : NTEDIT_E_DEVICE;
+}
+
+int
+ntedit_hip_filter_save_file(const ntedit_hip_ctx* c, int slot, const char* path)
+{
+	if (!c || slot < 0 || slot > 1 || !c->filt[slot].set || !path) {
+		return NTEDIT_E_ARG;
+	}
+	const DevFilter& f = c->filt[slot];
+	std::vector<u8> host(f.nbytes);
+	int rc = ntedit_hip_filter_download(c, slot, host.data());
+	if (rc) {
+		return rc;
+	}
+	nte_host::BfHeader h;
+	h.bytes = f.nbytes;
+	h.hash_num = f.hash_num;
+	h.k = f.k;
+	h.counting = f.counting;
+	return nte_host::bf_save(path, h, host.data()) ? NTEDIT_E_IO : 0;
+}
+
+int
+ntedit_hip_set_params(ntedit_hip_ctx* c, const ntedit_hip_params* p)
+{
+	if (!c || !p) {
+		return NTEDIT_E_ARG;
+	}
+	c->hp = *p;
+	c->dp_valid = false;
+	return 0;
+}
+
+int
+ntedit_hip_screen(ntedit_hip_ctx* c, const char* bases, uint64_t n, int on_device, uint64_t* bitmap)
+{
+	if (!c || !bases || !bitmap) {
+		return fail(c, NTEDIT_E_ARG, "screen: bad argument");
+	}
+	HIP_TRY(c, hipSetDevice(c->device));
+	int rc = refresh_params(c);
+	if (rc) {
+		return rc;
+	}
+	const u64 n_words = (n + 63) / 64;
+	const u8* d_seq = nullptr;
+	rc = stage_bases(c, bases, n, on_device, &d_seq);
+	if (rc) {
+		return rc;
+	}
+	u64* d_bitmap = bitmap;
+	if (!on_device) {
+		rc = ensure(c, c->bitmap, (n_words + 1) * 8);
+		if (rc) {
+			return rc;
+		}
+		d_bitmap = (u64*)c->bitmap.p;
+	}
+	HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+	rc = launch_screen<false>(c, d_seq, n, dev_filter(c->filt[0]), d_bitmap, n_words);
+	if (rc) {
+		return rc;
+	}
+	HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+	if (!on_device) {
+		HIP_TRY(c, hipMemcpyAsync(bitmap, d_bitmap, n_words * 8, hipMemcpyDeviceToHost, c->stream));
+	}
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev[0], c->ev[1]));
+	return 0;
+}
+
+int
+ntedit_hip_polish_batch(
+    ntedit_hip_ctx* c,
+    const char* bases,
+    uint64_t n,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    uint32_t n_contigs,
+    int on_device,
+    ntedit_hip_result** out)
+{
+	if (!c || !out || (n && !bases) || (n_contigs && (!offsets || !lens))) {
+		return fail(c, NTEDIT_E_ARG, "polish_batch: bad argument");
+	}
+	*out = nullptr;
+	HIP_TRY(c, hipSetDevice(c->device));
+	int rc = refresh_params(c);
+	if (rc) {
+		return rc;
+	}
+	for (u32 i = 0; i < n_contigs; i++) {
+		if (offsets[i] + lens[i] > n || (i + 1 < n_contigs && offsets[i] + lens[i] >= offsets[i + 1])) {
+			return fail(c, NTEDIT_E_ARG, "polish_batch: contig %u breaks the batch layout", i);
+		}
+	}
+	ntedit_hip_result* r = new ntedit_hip_result();
+	memset(&r->st, 0, sizeof r->st);
+	r->st.bases = n;
+	*out = r;
+	if (n == 0 || n_contigs == 0) {
+		return 0;
+	}
+	auto bail = [&](int code) {
+		delete r;
+		*out = nullptr;
+		return code;
+	};
+
+	const u64 n_words = (n + 63) / 64;
+	const u8* d_seq = nullptr;
+	if ((rc = stage_bases(c, bases, n, on_device, &d_seq))) {
+		return bail(rc);
+	}
+	if ((rc = ensure(c, c->bitmap, (n_words + 1) * 8)) || (rc = ensure(c, c->counters, 64)) ||
+	    (rc = ensure(c, c->offs, (size_t)n_contigs * 8)) || (rc = ensure(c, c->lens, (size_t)n_contigs * 4))) {
+		return bail(rc);
+	}
+	const u64 n_sblocks = (n_words + ST_TPB - 1) / ST_TPB;
+	if ((rc = ensure(c, c->block_counts, n_sblocks * 4)) || (rc = ensure(c, c->block_offsets, n_sblocks * 8))) {
+		return bail(rc);
+	}
+	u64* d_bitmap = (u64*)c->bitmap.p;
+	unsigned long long* d_counters = (unsigned long long*)c->counters.p;
+	hipStream_t s = c->stream;
+	HIP_TRY(c, hipMemcpyAsync(c->offs.p, offsets, (size_t)n_contigs * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n_contigs * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(c, hipMemsetAsync(d_counters, 0, 64, s));
+
+	// ---- step 1: screen
+	HIP_TRY(c, hipEventRecord(c->ev[0], s));
+	if ((rc = launch_screen<false>(c, d_seq, n, dev_filter(c->filt[0]), d_bitmap, n_words))) {
+		return bail(rc);
+	}
+	HIP_TRY(c, hipEventRecord(c->ev[1], s));
+
+	// ---- event starts
+	const u32 grid = c->dp.start_grid;
+	u64 grid_lo = 0;
+	if (grid < 64) {
+		for (u32 b = 0; b < 64; b += grid) {
+			grid_lo |= 1ULL << b;
+		}
+	}
+	hipLaunchKernelGGL(
+	    k_count_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, s, d_bitmap, n_words, grid_lo, grid,
+	    (u32*)c->block_counts.p, d_counters);
+	hipLaunchKernelGGL(
+	    k_scan_counts, dim3(1), dim3(1024), 0, s, (const u32*)c->block_counts.p, n_sblocks,
+	    (unsigned long long*)c->block_offsets.p, d_counters);
+	unsigned long long h_counters[2] = { 0, 0 };
+	HIP_TRY(c, hipMemcpyAsync(h_counters, d_counters, 16, hipMemcpyDeviceToHost, s));
+	HIP_TRY(c, hipStreamSynchronize(s));
+	const u64 n_events = h_counters[1];
+	r->st.absent_kmers = h_counters[0];
+	r->st.events = n_events;
+	if (n_events > 0) {
+		if ((rc = ensure(c, c->events, n_events * 8)) || (rc = ensure(c, c->first_chunk, n_events * 4))) {
+			return bail(rc);
+		}
+		hipLaunchKernelGGL(
+		    k_write_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, s, d_bitmap, n_words, grid_lo, grid,
+		    (const unsigned long long*)c->block_offsets.p, (u64*)c->events.p);
+	}
+	HIP_TRY(c, hipEventRecord(c->ev[2], s));
+	HIP_TRY(c, hipEventRecord(c->ev[3], s));
+
+	// ---- steps 2-5: event machine (retry with more room if it overflows)
+	if (n_events > 0) {
+		u64 arena_chunks = n_events + n_events / 2 + 4096;
+		for (int attempt = 0;; attempt++) {
+			const u64 max_threads = (u64)c->cu_count * 2048;
+			u64 threads = n_events < max_threads ? n_events : max_threads;
+			const u64 blocks = (threads + MACHINE_TPB - 1) / MACHINE_TPB;
+			threads = blocks * MACHINE_TPB;
+			const u64 W = c->dp.node_window;
+			if (arena_chunks > 0xFFFFFFF0ull) {
+				return bail(fail(c, NTEDIT_E_OVERFLOW, "edit-record arena exceeds 2^32 chunks"));
+			}
+			if ((rc = ensure(c, c->arena, arena_chunks * CHUNK_ITEMS * sizeof(Item))) ||
+			    (rc = ensure(c, c->ws_nodes, threads * W * sizeof(Node))) ||
+			    (rc = ensure(c, c->ws_ov_pos, threads * W * 4)) || (rc = ensure(c, c->ws_ov_chr, threads * W)) ||
+			    (rc = ensure(c, c->ws_prev, threads * W)) || (rc = ensure(c, c->ws_lps, threads * W * 2))) {
+				return bail(rc);
+			}
+			u32* d_arena_next = (u32*)((char*)c->counters.p + 32);
+			u32* d_status = (u32*)((char*)c->counters.p + 40);
+			HIP_TRY(c, hipMemsetAsync((char*)c->counters.p + 32, 0, 16, s));
+			MachineArgs a;
+			a.seq = d_seq;
+			a.offsets = (const u64*)c->offs.p;
+			a.lens = (const u32*)c->lens.p;
+			a.n_contigs = n_contigs;
+			a.bitmap = d_bitmap;
+			a.events = (const u64*)c->events.p;
+			a.n_events = n_events;
+			a.tabs = c->d_tab;
+			a.p = c->dp;
+			a.bloom = dev_filter(c->filt[0]);
+			a.rep = c->filt[1].set ? dev_filter(c->filt[1]) : dev_filter(c->filt[0]);
+			a.ws_nodes = (Node*)c->ws_nodes.p;
+			a.ws_ov_pos = (u32*)c->ws_ov_pos.p;
+			a.ws_ov_chr = (u8*)c->ws_ov_chr.p;
+			a.ws_prev = (u8*)c->ws_prev.p;
+			a.ws_lps = (int16_t*)c->ws_lps.p;
+			a.arena = (Item*)c->arena.p;
+			a.arena_next = d_arena_next;
+			a.arena_chunks = (u32)arena_chunks;
+			a.first_chunk = (u32*)c->first_chunk.p;
+			a.status = d_status;
+			HIP_TRY(c, hipEventRecord(c->ev[3], s));
+			hipLaunchKernelGGL(k_machine, dim3((unsigned)blocks), dim3(MACHINE_TPB), 0, s, a);
+			HIP_TRY(c, hipGetLastError());
+			HIP_TRY(c, hipEventRecord(c->ev[4], s));
+			u32 h_tail[4] = { 0, 0, 0, 0 };
+			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, s));
+			HIP_TRY(c, hipStreamSynchronize(s));
+			const u32 used = h_tail[0], status = h_tail[2];
+			if (status == 0) {
+				const u64 used_chunks = used < arena_chunks ? used : arena_chunks;
+				r->arena.resize((size_t)used_chunks * CHUNK_ITEMS);
+				std::vector<u32> first(n_events);
+				if (used_chunks) {
+					HIP_TRY(c, hipMemcpyAsync(r->arena.data(), c->arena.p, r->arena.size() * sizeof(Item), hipMemcpyDeviceToHost, s));
+				}
+				HIP_TRY(c, hipMemcpyAsync(first.data(), c->first_chunk.p, n_events * 4, hipMemcpyDeviceToHost, s));
+				HIP_TRY(c, hipStreamSynchronize(s));
+				r->ev_first.reserve(used_chunks);
+				for (u64 i = 0; i < n_events; i++) {
+					if (first[i] != NONE32) {
+						r->ev_first.push_back(first[i]);
+					}
+				}
+				break;
+			}
+			if (attempt >= 4) {
+				return bail(fail(c, NTEDIT_E_OVERFLOW, "event machine ran out of room (status %u)", status));
+			}
+			if (status & EV_ARENA_FULL) {
+				arena_chunks *= 4;
+			}
+			if (status & EV_OVERFLOW) {
+				c->dp.node_window *= 2;
+			}
+		}
+	} else {
+		HIP_TRY(c, hipEventRecord(c->ev[4], s));
+		HIP_TRY(c, hipStreamSynchronize(s));
+	}
+	HIP_TRY(c, hipEventElapsedTime(&r->st.ms_screen, c->ev[0], c->ev[1]));
+	HIP_TRY(c, hipEventElapsedTime(&r->st.ms_extract, c->ev[1], c->ev[2]));
+	HIP_TRY(c, hipEventElapsedTime(&r->st.ms_machine, c->ev[3], c->ev[4]));
+	HIP_TRY(c, hipEventElapsedTime(&r->st.ms_total, c->ev[0], c->ev[4]));
+	c->last_ms = r->st.ms_screen;
+	return 0;
+}
+
+void
+ntedit_hip_result_free(ntedit_hip_result* r)
+{
+	delete r;
+}
+
+int
+ntedit_hip_result_stats(const ntedit_hip_result* r, ntedit_hip_stats* s)
+{
+	if (!r || !s) {
+		return NTEDIT_E_ARG;
+	}
+	*s = r->st;
+	s->events_applied = r->rst.events_applied;
+	s->substitutions = r->rst.substitutions;
+	s->insertions = r->rst.insertions;
+	s->deletions = r->rst.deletions;
+	return 0;
+}
+
+int
+ntedit_hip_write_outputs(
+    const ntedit_hip_result* r,
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    const char* fa_path,
+    const char* tsv_path,
+    int append)
+{
+	if (!r || (n_contigs && (!bases || !offsets || !lens || !names))) {
+		return NTEDIT_E_ARG;
+	}
+	FILE* fa = fa_path ? fopen(fa_path, append ? "ab" : "wb") : nullptr;
+	FILE* tsv = tsv_path ? fopen(tsv_path, append ? "ab" : "wb") : nullptr;
+	if ((fa_path && !fa) || (tsv_path && !tsv)) {
+		if (fa) {
+			fclose(fa);
+		}
+		if (tsv) {
+			fclose(tsv);
+		}
+		return NTEDIT_E_IO;
+	}
+	if (fa) {
+		setvbuf(fa, nullptr, _IOFBF, 4 << 20);
+	}
+	if (tsv) {
+		setvbuf(tsv, nullptr, _IOFBF, 1 << 20);
+	}
+	ntedit_hip_result* rw = const_cast<ntedit_hip_result*>(r);
+	rw->rst = nte_host::RenderStats();
+	int rc = nte_host::render_batch(
+	    r->arena.data(),
+	    r->arena.size(),
+	    r->ev_first.data(),
+	    r->ev_first.size(),
+	    bases,
+	    offsets,
+	    lens,
+	    names,
+	    n_contigs,
+	    fa,
+	    tsv,
+	    &rw->rst);
+	if (fa && fclose(fa) != 0) {
+		rc = rc ? rc : NTEDIT_E_IO;
+	}
+	if (tsv && fclose(tsv) != 0) {
+		rc = rc ? rc : NTEDIT_E_IO;
+	}
+	return rc ? NTEDIT_E_IO : 0;
+}
+
+int
+ntedit_hip_write_tsv_header(const char* tsv_path, uint32_t k, uint32_t jump, int counting)
+{
+	FILE* tsv = fopen(tsv_path, "wb");
+	if (!tsv) {
+		return NTEDIT_E_IO;
+	}
+	nte_host::write_tsv_header(tsv, k, jump, counting != 0);
+	return fclose(tsv) == 0 ? 0 : NTEDIT_E_IO;
+}
+
+float
+ntedit_hip_last_kernel_ms(const ntedit_hip_ctx* c)
+{
+	return c ? c->last_ms : 0.f;
+}
+
+int
+ntedit_hip_gather_bench(ntedit_hip_ctx* c, uint64_t nbytes, uint64_t n_probes, double* probes_per_s, float* ms)
+{
+	if (!c || nbytes < 4096 || (nbytes & (nbytes - 1))) {
+		return fail(c, NTEDIT_E_ARG, "gather_bench: nbytes must be a power of two");
+	}
+	HIP_TRY(c, hipSetDevice(c->device));
+	u8* buf = nullptr;
+	u32* sink = nullptr;
+	HIP_TRY(c, hipMalloc((void**)&buf, nbytes));
+	HIP_TRY(c, hipMalloc((void**)&sink, 64));
+	HIP_TRY(c, hipMemset(buf, 0x5A, nbytes));
+	const u64 threads = (u64)c->cu_count * 2048 * 2;
+	u64 per_thread = (n_probes + threads - 1) / threads;
+	per_thread = (per_thread + 11) / 12 * 12;
+	const u64 mask = nbytes * 8 - 1;
+	// warm-up + timed run
+	hipLaunchKernelGGL(k_gather, dim3((unsigned)(threads / 256)), dim3(256), 0, c->stream, buf, mask, (u64)12, sink);
+	HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+	hipLaunchKernelGGL(k_gather, dim3((unsigned)(threads / 256)), dim3(256), 0, c->stream, buf, mask, per_thread, sink);
+	HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	float t = 0.f;
+	HIP_TRY(c, hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
+	(void)hipFree(buf);
+	(void)hipFree(sink);
+	if (ms) {
+		*ms = t;
+	}
+	if (probes_per_s) {
+		*probes_per_s = (double)(per_thread * threads) / ((double)t * 1e-3);
+	}
+	c->last_ms = t;
+	return 0;
+}
+
+} // extern "C"

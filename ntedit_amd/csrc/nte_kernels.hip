@@ -1,0 +1,474 @@
+// nte_kernels.hip -- gfx950 kernels of the ntEdit hot path.
+//
+//   k_screen        step 1 of the reference's per-contig loop for EVERY k-mer of
+//                   a batch at once: rolling forward+reverse ntHash, h-way
+//                   Bloom-filter probe, 1 "absent" bit per k-mer start
+//                   (ntedit.cpp:1798-1807 + the roll at 2119-2138).  Also the
+//                   filter build (insert) variant.
+//   k_count_starts / k_scan_counts / k_write_starts
+//                   turn the absent bitmap into the ordered list of event starts
+//   k_machine       one thread per event: steps 2-5 + makeEdit (nte_machine.h)
+//   k_gather        random 1-byte gather micro-benchmark (roofline denominator)
+//
+// Roofline: all of this is integer hashing + random 1-byte gathers from a
+// multi-GiB bit array => HBM random-read bound; no MFMA anywhere.
+#include "nte_machine.h"
+
+#include <hip/hip_runtime.h>
+
+namespace nte {
+
+// ------------------------------------------------------------------ k_screen
+// Tile: 256 threads x 64 consecutive k-mer starts per thread = 16384 starts per
+// workgroup.  The tile's bases (+ k-1 halo) are loaded once, coalesced 16 B per
+// lane, translated to 4-bit character codes through an LDS LUT and parked in
+// LDS as one code per byte.  Rows of 64 codes are padded to 68 bytes so that
+// the per-thread streams (lane stride = one row) hit 32 different banks.
+constexpr int SCREEN_TPB = 256;
+constexpr int SCREEN_L = 64;
+constexpr int SCREEN_TILE = SCREEN_TPB * SCREEN_L;
+constexpr int SCREEN_MAXK = 256;
+constexpr int SCREEN_LDS_BYTES = ((SCREEN_TILE + SCREEN_MAXK + 63) / 64) * 68 + 16;
+
+__device__ __forceinline__ u32
+lds_phys(u32 x)
+{
+	return x + ((x >> 6) << 2);
+}
+
+template<int H, bool POW2, bool INSERT>
+__global__ __launch_bounds__(SCREEN_TPB) void
+k_screen(
+    const u8* __restrict__ seq,
+    u64 n,
+    Filter f,
+    DevParams p,
+    const u64* __restrict__ tabs,
+    u64* __restrict__ bitmap,
+    u64 n_words)
+{
+	__shared__ u64 s_tab[TAB_WORDS];
+	__shared__ u8 s_lut[256];
+	__shared__ __attribute__((aligned(16))) u8 s_codes[SCREEN_LDS_BYTES];
+
+	const u32 tid = threadIdx.x;
+	if (tid < TAB_WORDS) {
+		s_tab[tid] = tabs[tid];
+	}
+	{
+		u8 code = char_code((u8)tid);
+		if (INSERT && code > 3) {
+			code = CODE_BAD; // the filter build takes ACGT-only k-mers
+		}
+		s_lut[tid] = code;
+	}
+	__syncthreads();
+
+	const u64 tile_base = (u64)blockIdx.x * SCREEN_TILE;
+	const u32 k = p.k;
+	// ---- stage the tile: 16-byte chunks, translated to codes
+	const u32 n_chunks = (SCREEN_TILE + k - 1 + 15) / 16;
+	for (u32 c = tid; c < n_chunks; c += SCREEN_TPB) {
+		const u64 g = tile_base + (u64)c * 16;
+		u32 w[4];
+		if (g + 16 <= n) {
+			const uint4 v = *reinterpret_cast<const uint4*>(seq + g);
+			w[0] = v.x;
+			w[1] = v.y;
+			w[2] = v.z;
+			w[3] = v.w;
+		} else {
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				u32 x = 0;
+#pragma unroll
+				for (int b = 0; b < 4; b++) {
+					const u64 gg = g + q * 4 + b;
+					const u32 ch = gg < n ? seq[gg] : (u32)'\n';
+					x |= ch << (8 * b);
+				}
+				w[q] = x;
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const u32 x = w[q];
+			const u32 codes = (u32)s_lut[x & 0xFF] | ((u32)s_lut[(x >> 8) & 0xFF] << 8) |
+			                  ((u32)s_lut[(x >> 16) & 0xFF] << 16) | ((u32)s_lut[x >> 24] << 24);
+			*reinterpret_cast<u32*>(&s_codes[lds_phys(c * 16 + q * 4)]) = codes;
+		}
+	}
+	__syncthreads();
+
+	// ---- per-thread stream of 64 k-mer starts
+	const u32 x0 = tid * SCREEN_L;
+	HashState hs = { 0, 0 };
+	u32 good = 0;
+	for (u32 i = 0; i < k; i++) {
+		const u8 in = s_codes[lds_phys(x0 + i)];
+		hash_roll(hs, s_tab, CODE_BAD, in);
+		good = in == CODE_BAD ? 0 : good + 1;
+	}
+
+	const u32 ksh = (k & 3) * 8;
+	u64 bits = 0;
+	u32 in_lo = *reinterpret_cast<const u32*>(&s_codes[lds_phys((x0 + k) & ~3u)]);
+	for (u32 j0 = 0; j0 < SCREEN_L; j0 += 4) {
+		const u32 outw = *reinterpret_cast<const u32*>(&s_codes[lds_phys(x0 + j0)]);
+		const u32 in_hi = *reinterpret_cast<const u32*>(&s_codes[lds_phys(((x0 + j0 + k) & ~3u) + 4)]);
+		const u32 inw = ksh ? ((in_lo >> ksh) | (in_hi << (32 - ksh))) : in_lo;
+		in_lo = in_hi;
+
+		u64 slot[4][H > 0 ? H : 1];
+		bool valid[4];
+		u64 base4[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			valid[u] = good >= k;
+			const u64 base = hs.fh + hs.rh;
+			base4[u] = base;
+			if (H > 0) {
+#pragma unroll
+				for (int i = 0; i < (H > 0 ? H : 1); i++) {
+					const u64 hv = hash_extend(base, p, i);
+					slot[u][i] = POW2 ? (hv & f.mask) : (hv % f.bits);
+				}
+			}
+			const u8 out = (outw >> (8 * u)) & 0xFF;
+			const u8 in = (inw >> (8 * u)) & 0xFF;
+			hash_roll(hs, s_tab, out, in);
+			good = in == CODE_BAD ? 0 : good + 1;
+		}
+
+		if (INSERT) {
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				if (valid[u]) {
+					if (H > 0) {
+#pragma unroll
+						for (int i = 0; i < (H > 0 ? H : 1); i++) {
+							const u64 s = slot[u][i];
+							atomicOr(
+							    reinterpret_cast<u32*>(const_cast<u8*>(f.data)) + (s >> 5),
+							    1u << (s & 31));
+						}
+					} else {
+						for (u32 i = 0; i < f.hash_num; i++) {
+							const u64 s = filter_slot(f, hash_extend(base4[u], p, i));
+							atomicOr(
+							    reinterpret_cast<u32*>(const_cast<u8*>(f.data)) + (s >> 5),
+							    1u << (s & 31));
+						}
+					}
+				}
+			}
+		} else {
+			if (H > 0) {
+				u8 byte[4][H > 0 ? H : 1];
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+#pragma unroll
+					for (int i = 0; i < (H > 0 ? H : 1); i++) {
+						// invalid k-mers read byte 0 instead of branching: keeps all
+						// 4*H gathers independent and in flight together
+						byte[u][i] = f.data[valid[u] ? (slot[u][i] >> 3) : 0];
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					u32 present = 1;
+#pragma unroll
+					for (int i = 0; i < (H > 0 ? H : 1); i++) {
+						present &= (byte[u][i] >> (slot[u][i] & 7)) & 1;
+					}
+					if (valid[u] && !present) {
+						bits |= 1ULL << (j0 + u);
+					}
+				}
+			} else {
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					if (valid[u]) {
+						bool present = true;
+						for (u32 i = 0; i < f.hash_num && present; i++) {
+							const u64 s = filter_slot(f, hash_extend(base4[u], p, i));
+							present = (f.data[s >> 3] >> (s & 7)) & 1;
+						}
+						if (!present) {
+							bits |= 1ULL << (j0 + u);
+						}
+					}
+				}
+			}
+		}
+	}
+	if (!INSERT) {
+		const u64 w = (u64)blockIdx.x * SCREEN_TPB + tid;
+		if (w < n_words) {
+			bitmap[w] = bits;
+		}
+	}
+}
+
+// ------------------------------------------------------------ event starts
+__device__ __forceinline__ u64
+start_mask(const u64* __restrict__ bitmap, u64 w, u64 grid_lo, u32 grid)
+{
+	const u64 m = bitmap[w];
+	if (m == 0) {
+		return 0;
+	}
+	const u64 prev = w ? (bitmap[w - 1] >> 63) : 0;
+	const u64 shifted = (m << 1) | prev;
+	u64 gm = grid_lo;
+	if (grid >= 64) {
+		gm = ((w * 64) % grid) == 0 ? 1ULL : 0ULL;
+	}
+	return m & (~shifted | gm);
+}
+
+constexpr int ST_TPB = 256;
+
+// counters[0] += absent k-mers ; block_counts[b] = starts in block b
+__global__ __launch_bounds__(ST_TPB) void
+k_count_starts(
+    const u64* __restrict__ bitmap,
+    u64 n_words,
+    u64 grid_lo,
+    u32 grid,
+    u32* __restrict__ block_counts,
+    unsigned long long* __restrict__ counters)
+{
+	__shared__ u32 s_cnt[ST_TPB / 64];
+	__shared__ u32 s_abs[ST_TPB / 64];
+	const u64 w = (u64)blockIdx.x * ST_TPB + threadIdx.x;
+	u32 c = 0, a = 0;
+	if (w < n_words) {
+		c = __popcll(start_mask(bitmap, w, grid_lo, grid));
+		a = __popcll(bitmap[w]);
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		c += __shfl_down(c, off, 64);
+		a += __shfl_down(a, off, 64);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		s_cnt[threadIdx.x >> 6] = c;
+		s_abs[threadIdx.x >> 6] = a;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		u32 tc = 0, ta = 0;
+		for (int i = 0; i < ST_TPB / 64; i++) {
+			tc += s_cnt[i];
+			ta += s_abs[i];
+		}
+		block_counts[blockIdx.x] = tc;
+		if (ta) {
+			atomicAdd(&counters[0], (unsigned long long)ta);
+		}
+	}
+}
+
+// exclusive scan of block_counts (single workgroup); counters[1] = total
+__global__ __launch_bounds__(1024) void
+k_scan_counts(
+    const u32* __restrict__ block_counts,
+    u64 n_blocks,
+    unsigned long long* __restrict__ block_offsets,
+    unsigned long long* __restrict__ counters)
+{
+	__shared__ unsigned long long s_part[1024];
+	__shared__ unsigned long long s_carry;
+	if (threadIdx.x == 0) {
+		s_carry = 0;
+	}
+	__syncthreads();
+	for (u64 base = 0; base < n_blocks; base += 1024) {
+		const u64 i = base + threadIdx.x;
+		const unsigned long long v = i < n_blocks ? block_counts[i] : 0;
+		s_part[threadIdx.x] = v;
+		__syncthreads();
+		// Hillis-Steele inclusive scan
+		for (int off = 1; off < 1024; off <<= 1) {
+			unsigned long long t = 0;
+			if ((int)threadIdx.x >= off) {
+				t = s_part[threadIdx.x - off];
+			}
+			__syncthreads();
+			s_part[threadIdx.x] += t;
+			__syncthreads();
+		}
+		const unsigned long long incl = s_part[threadIdx.x];
+		const unsigned long long carry = s_carry;
+		if (i < n_blocks) {
+			block_offsets[i] = carry + incl - v;
+		}
+		__syncthreads();
+		if (threadIdx.x == 1023) {
+			s_carry = carry + incl;
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		counters[1] = s_carry;
+	}
+}
+
+__global__ __launch_bounds__(ST_TPB) void
+k_write_starts(
+    const u64* __restrict__ bitmap,
+    u64 n_words,
+    u64 grid_lo,
+    u32 grid,
+    const unsigned long long* __restrict__ block_offsets,
+    u64* __restrict__ events)
+{
+	__shared__ u32 s_scan[ST_TPB];
+	const u64 w = (u64)blockIdx.x * ST_TPB + threadIdx.x;
+	u64 m = 0;
+	if (w < n_words) {
+		m = start_mask(bitmap, w, grid_lo, grid);
+	}
+	const u32 c = __popcll(m);
+	s_scan[threadIdx.x] = c;
+	__syncthreads();
+	for (int off = 1; off < ST_TPB; off <<= 1) {
+		u32 t = 0;
+		if ((int)threadIdx.x >= off) {
+			t = s_scan[threadIdx.x - off];
+		}
+		__syncthreads();
+		s_scan[threadIdx.x] += t;
+		__syncthreads();
+	}
+	u64 o = block_offsets[blockIdx.x] + (s_scan[threadIdx.x] - c);
+	while (m) {
+		const int b = __ffsll((long long)m) - 1;
+		events[o++] = w * 64 + b;
+		m &= m - 1;
+	}
+}
+
+// ----------------------------------------------------------------- k_machine
+struct MachineArgs
+{
+	const u8* seq;
+	const u64* offsets; // start of every contig in the batch
+	const u32* lens;
+	u32 n_contigs;
+	const u64* bitmap;
+	const u64* events;
+	u64 n_events;
+	const u64* tabs;
+	DevParams p;
+	Filter bloom, rep;
+	// per-thread workspace slabs
+	Node* ws_nodes;
+	u32* ws_ov_pos;
+	u8* ws_ov_chr;
+	u8* ws_prev;
+	int16_t* ws_lps;
+	// output
+	Item* arena;
+	u32* arena_next;
+	u32 arena_chunks;
+	u32* first_chunk; // per event
+	u32* status;      // OR of EV_OVERFLOW / EV_ARENA_FULL seen
+};
+
+constexpr int MACHINE_TPB = 256;
+
+__global__ __launch_bounds__(MACHINE_TPB) void
+k_machine(MachineArgs a)
+{
+	__shared__ u64 s_tab[TAB_WORDS];
+	if (threadIdx.x < TAB_WORDS) {
+		s_tab[threadIdx.x] = a.tabs[threadIdx.x];
+	}
+	__syncthreads();
+	const u64 tid = (u64)blockIdx.x * MACHINE_TPB + threadIdx.x;
+	const u64 nthreads = (u64)gridDim.x * MACHINE_TPB;
+	const u64 W = a.p.node_window;
+
+	EventEnv env;
+	env.bitmap = a.bitmap;
+	env.tab = s_tab;
+	env.p = &a.p;
+	env.bloom = a.bloom;
+	env.rep = a.rep;
+	env.nodes = a.ws_nodes + tid * W;
+	env.ov_pos = a.ws_ov_pos + tid * W;
+	env.ov_chr = a.ws_ov_chr + tid * W;
+	env.prev = a.ws_prev + tid * W;
+	env.lps = a.ws_lps + tid * W;
+	env.arena = a.arena;
+	env.arena_next = a.arena_next;
+	env.arena_chunks = a.arena_chunks;
+
+	for (u64 ev = tid; ev < a.n_events; ev += nthreads) {
+		const u64 g = a.events[ev];
+		// contig of g: last offset <= g
+		u32 lo = 0, hi = a.n_contigs;
+		while (hi - lo > 1) {
+			const u32 mid = lo + ((hi - lo) >> 1);
+			if (a.offsets[mid] <= g) {
+				lo = mid;
+			} else {
+				hi = mid;
+			}
+		}
+		env.contig = lo;
+		env.gbase = a.offsets[lo];
+		env.seq = a.seq + env.gbase;
+		env.len = a.lens[lo];
+		const u32 start = (u32)(g - env.gbase);
+		u32 fc = NONE32;
+		if ((u64)start + a.p.k <= env.len) {
+			Machine m(env);
+			u32 cover_end = start;
+			m.run(start, cover_end);
+			fc = m.finish(start, cover_end);
+			if (m.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
+				atomicOr(a.status, m.flags & (EV_OVERFLOW | EV_ARENA_FULL));
+			}
+		}
+		a.first_chunk[ev] = fc;
+	}
+}
+
+// ------------------------------------------------------------------ k_gather
+// Uniform random 1-byte gathers, 12 independent loads in flight per lane
+// (the same depth k_screen uses at h=3): the random-read roofline reference.
+__global__ __launch_bounds__(256) void
+k_gather(const u8* __restrict__ data, u64 mask, u64 per_thread, u32* __restrict__ sink)
+{
+	u64 x = ((u64)blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ULL + 0x1234567ULL;
+	u32 acc = 0;
+	for (u64 it = 0; it < per_thread; it += 12) {
+		u64 a[12];
+#pragma unroll
+		for (int i = 0; i < 12; i++) {
+			x ^= x << 13;
+			x ^= x >> 7;
+			x ^= x << 17;
+			a[i] = (x * 0x2545F4914F6CDD1DULL) & mask;
+		}
+		u8 b[12];
+#pragma unroll
+		for (int i = 0; i < 12; i++) {
+			b[i] = data[a[i] >> 3];
+		}
+#pragma unroll
+		for (int i = 0; i < 12; i++) {
+			acc += (b[i] >> (a[i] & 7)) & 1;
+		}
+	}
+	if (acc == 0xFFFFFFFFu) {
+		sink[0] = acc;
+	}
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		sink[1] = acc;
+	}
+}
+
+} // namespace nte

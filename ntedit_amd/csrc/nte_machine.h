@@ -32,8 +32,6 @@ namespace nte {
 #define NTE_ATOMIC_INC(p) ((*(p))++)
 #endif
 
-constexpr u32 PREV_CAP = 512; // longest run of inserted characters examined (>= 1.5k + 16)
-
 struct EventEnv
 {
 	const u8* seq;  // contig bases
@@ -48,6 +46,8 @@ struct EventEnv
 	Node* nodes;
 	u32* ov_pos;
 	u8* ov_chr;
+	u8* prev;      // scratch for the previous-insertion string (node_window bytes)
+	int16_t* lps;  // scratch for its KMP failure table (node_window entries)
 	// output arena
 	Item* arena;
 	u32* arena_next;
@@ -607,7 +607,7 @@ struct Machine
 			idx--;
 		}
 		while (idx < nsize && idx >= nbase && nget(idx).type == 1) {
-			if (n < PREV_CAP) {
+			if (n + 16 < p.node_window) {
 				out[n] = rc_char(nget(idx).c);
 			}
 			n++;
@@ -882,10 +882,10 @@ struct Machine
 		}
 		case 2: {
 			bool skipped_repeat = false;
-			u8 prev[PREV_CAP + 16];
-			int16_t lps[PREV_CAP + 16];
+			u8* prev = e.prev;
+			int16_t* lps = e.lps;
 			u32 n_prev = get_prev_insertion(prev);
-			if (n_prev + 12 > PREV_CAP) {
+			if (n_prev + 16 >= p.node_window) {
 				flags |= EV_OVERFLOW;
 				break;
 			}

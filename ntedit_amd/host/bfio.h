@@ -1,0 +1,34 @@
+// bfio.h -- btllib Bloom-filter file header IO (host side).
+//
+// Format (btllib BloomFilter::save, restated from its published behaviour --
+// btllib itself is not in the reference tree, so this is "parity unpinned",
+// see DESIGN.md): a TOML-ish text header
+//     [BTLKmerBloomFilter_vN]          (or [BTLKmerCountingBloomFilter_vN])
+//     bytes = <array bytes>
+//     hash_num = <h>
+//     hash_fn = "ntHash_v2"
+//     k = <k>
+//     [HeaderEnd]
+// followed by the raw array.  Keys may come in any order (cpptoml tables are
+// unordered); unknown keys are ignored; any _vN suffix is accepted.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+
+namespace nte_host {
+
+struct BfHeader
+{
+	uint64_t bytes = 0;
+	uint32_t hash_num = 0;
+	uint32_t k = 0;
+	bool counting = false;
+};
+
+// opens the file and parses the header; on success the returned FILE* is
+// positioned at the first byte of the array.  nullptr on any error.
+FILE* bf_open(const char* path, BfHeader* h);
+// writes header + array; 0 on success
+int bf_save(const char* path, const BfHeader& h, const uint8_t* data);
+
+} // namespace nte_host

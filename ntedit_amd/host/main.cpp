@@ -1,0 +1,469 @@
+// main.cpp -- `ntedit` host driver for the MI355X hot path.
+//
+// Keeps the reference's command-line surface (ntedit.cpp:135-169, 2276-2364):
+//   -t -f -r -e -b -z -i -d -x -y -X -Y -c -j -m -s -l -a -v -p -q -k --help --version
+// (-k is accepted and ignored, exactly like the reference: k comes from the
+// Bloom filter header; -c is parsed and overwritten by k*1.5; -t has no effect
+// because contigs are processed on the GPU, output order is the input order,
+// i.e. the reference at -t 1).  Reads the draft with kseq semantics, batches
+// contigs, calls the C ABI (include/ntedit_hip.h) and writes
+// <prefix>_edited.fa and <prefix>_changes.tsv byte-identically to the
+// reference.  <prefix>_variants.vcf gets the reference's header lines only
+// (the VCF body is outside this path's parity contract).
+#include "../../include/ntedit_hip.h"
+#include "fasta.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <getopt.h>
+#include <sstream>
+#include <string>
+#include <unistd.h>
+#include <vector>
+
+#define PROGRAM "ntEdit v2.1.1"
+
+static const char USAGE[] = PROGRAM
+    " (MI355X HIP hot path)\n\n"
+    " Options:\n"
+    "	-t,	number of threads (accepted; contigs are polished on the GPU)\n"
+    "	-f,	draft genome assembly (FASTA, Multi-FASTA, and/or gzipped compatible), REQUIRED\n"
+    "	-r,	Bloom filter (BF) file (btllib format, e.g. from ntStat v1.0.0+), REQUIRED\n"
+    "	-e,	secondary BF with k-mers to reject, OPTIONAL\n"
+    "	-b,	output file prefix, OPTIONAL\n"
+    "	-z,	minimum contig length [default=100]\n"
+    "	-i,	maximum number of insertion bases to try, range 0-5, [default=5]\n"
+    "	-d,	maximum number of deletions bases to try, range 0-10, [default=5]\n"
+    "	-x,	k/x ratio for the number of k-mers that should be missing, [default=5.000]\n"
+    "	-y, 	k/y ratio for the number of edited k-mers that should be present, [default=9.000]\n"
+    "	-X, 	ratio of number of k-mers in the k subset that should be missing, [default=0.5]\n"
+    "	-Y, 	ratio of number of k-mers in the k subset that should be present, [default=0.5]\n"
+    "	-c,	cap for the number of base insertions at one position (parsed; k*1.5 is used)\n"
+    "	-j, 	controls size of k-mer subset, check every jth k-mer, [default=3]\n"
+    "	-m,	mode of editing, range 0-2, [default=0]\n"
+    "	-s,     SNV mode (not available on the HIP path yet)\n"
+    "	-l,	input VCF file with annotated variants (accepted, unused on this path)\n"
+    "	-a,	soft masks missing k-mer positions having no fix (1 = yes, default = 0, no)\n"
+    "	-v,	verbose mode (accepted)\n"
+    "	-p, -q, k-mer coverage thresholds (counting BF only; not available on the HIP path yet)\n"
+    "	--gpu N,	HIP device index [default=0]\n"
+    "	--batch-bases N,	bases per GPU batch [default=1073741824]\n"
+    "	--shard I/N,	polish only every contig whose index mod N == I (multi-GPU sharding)\n"
+    "	--help,		display this message and exit \n"
+    "	--version,	output version information and exit\n\n";
+
+static const char shortopts[] = "t:f:s:k:z:b:r:v:d:i:X:Y:x:y:m:c:j:s:e:a:l:p:q:";
+enum
+{
+	OPT_HELP = 1000,
+	OPT_VERSION,
+	OPT_GPU,
+	OPT_BATCH,
+	OPT_SHARD,
+	OPT_REPORT
+};
+static const struct option longopts[] = {
+	{ "threads", required_argument, nullptr, 't' },
+	{ "draft_file", required_argument, nullptr, 'f' },
+	{ "k", required_argument, nullptr, 'k' },
+	{ "minimum_contig_length", required_argument, nullptr, 'z' },
+	{ "maximum_insertions", required_argument, nullptr, 'i' },
+	{ "maximum_deletions", required_argument, nullptr, 'd' },
+	{ "insertion_cap", required_argument, nullptr, 'c' },
+	{ "edit_threshold", required_argument, nullptr, 'y' },
+	{ "missing_threshold", required_argument, nullptr, 'x' },
+	{ "edit_ratio", required_argument, nullptr, 'Y' },
+	{ "missing_ratio", required_argument, nullptr, 'X' },
+	{ "jump", required_argument, nullptr, 'j' },
+	{ "bloom_filename", required_argument, nullptr, 'r' },
+	{ "bloomrep_filename", required_argument, nullptr, 'e' },
+	{ "outfile_prefix", required_argument, nullptr, 'b' },
+	{ "mode", required_argument, nullptr, 'm' },
+	{ "snv", required_argument, nullptr, 's' },
+	{ "vcf_file", required_argument, nullptr, 'l' },
+	{ "mask", required_argument, nullptr, 'a' },
+	{ "verbose", required_argument, nullptr, 'v' },
+	{ "minimum_kmer_coverage", required_argument, nullptr, 'p' },
+	{ "maximum_kmer_coverage", required_argument, nullptr, 'q' },
+	{ "gpu", required_argument, nullptr, OPT_GPU },
+	{ "batch-bases", required_argument, nullptr, OPT_BATCH },
+	{ "shard", required_argument, nullptr, OPT_SHARD },
+	{ "report", no_argument, nullptr, OPT_REPORT },
+	{ "help", no_argument, nullptr, OPT_HELP },
+	{ "version", no_argument, nullptr, OPT_VERSION },
+	{ nullptr, 0, nullptr, 0 }
+};
+
+static void
+die_unreadable(const std::string& path)
+{
+	// ntedit.cpp:476-483
+	if (access(path.c_str(), R_OK) == -1) {
+		fprintf(stderr, PROGRAM ": error: `%s': %s\n", path.c_str(), strerror(errno));
+		exit(EXIT_FAILURE);
+	}
+}
+
+static std::string
+base_name(const std::string& p)
+{
+	return p.substr(p.find_last_of("/\\") + 1);
+}
+
+template<typename T>
+static void
+parse(int c, const char* arg, T& out)
+{
+	std::istringstream ss(arg ? arg : "");
+	ss >> out;
+	if (arg && (!ss.eof() || ss.fail())) {
+		// ntedit.cpp:2360-2363
+		fprintf(stderr, PROGRAM ": invalid option: `-%c%s'\n", (char)c, arg);
+		exit(EXIT_FAILURE);
+	}
+}
+
+struct Batch
+{
+	std::string blob;
+	std::vector<uint64_t> offs;
+	std::vector<uint32_t> lens;
+	std::vector<std::string> names;
+	void clear()
+	{
+		blob.clear();
+		offs.clear();
+		lens.clear();
+		names.clear();
+	}
+};
+
+int
+main(int argc, char** argv)
+{
+	ntedit_hip_params p;
+	ntedit_hip_params_default(&p);
+	std::string draft, bf, bfrep, prefix, vcf;
+	unsigned nthreads = 4, ignored_u = 0;
+	int verbose = 0, gpu = 0, report = 0;
+	unsigned long long batch_bases = 1ull << 30;
+	unsigned shard_i = 0, shard_n = 1;
+	bool die = false;
+	for (int c; (c = getopt_long(argc, argv, shortopts, longopts, nullptr)) != -1;) {
+		switch (c) {
+		case '?':
+			die = true;
+			break;
+		case 't':
+			parse(c, optarg, nthreads);
+			break;
+		case 'f':
+			parse(c, optarg, draft);
+			break;
+		case 'z':
+			parse(c, optarg, p.min_contig_len);
+			break;
+		case 'b':
+			parse(c, optarg, prefix);
+			break;
+		case 'r':
+			parse(c, optarg, bf);
+			break;
+		case 'e':
+			parse(c, optarg, bfrep);
+			break;
+		case 'd':
+			parse(c, optarg, p.max_deletions);
+			break;
+		case 'i':
+			parse(c, optarg, p.max_insertions);
+			break;
+		case 'x':
+			parse(c, optarg, p.missing_threshold);
+			break;
+		case 'y':
+			parse(c, optarg, p.edit_threshold);
+			break;
+		case 'X':
+			parse(c, optarg, p.missing_ratio);
+			p.use_ratio = 1;
+			break;
+		case 'Y':
+			parse(c, optarg, p.edit_ratio);
+			p.use_ratio = 1;
+			break;
+		case 'c':
+			parse(c, optarg, ignored_u); // overwritten by k*1.5 (ntedit.cpp:2450)
+			break;
+		case 'j':
+			parse(c, optarg, p.jump);
+			break;
+		case 'm':
+			parse(c, optarg, p.mode);
+			break;
+		case 's':
+			parse(c, optarg, p.snv);
+			break;
+		case 'l':
+			parse(c, optarg, vcf);
+			break;
+		case 'a':
+			parse(c, optarg, p.mask);
+			break;
+		case 'v':
+			parse(c, optarg, verbose);
+			break;
+		case 'p':
+			parse(c, optarg, p.min_threshold);
+			break;
+		case 'q':
+			parse(c, optarg, p.max_threshold);
+			break;
+		case 'k':
+			break; // accepted and ignored, like the reference (no `case 'k'` there)
+		case OPT_GPU:
+			parse(c, optarg, gpu);
+			break;
+		case OPT_BATCH:
+			parse(c, optarg, batch_bases);
+			break;
+		case OPT_SHARD:
+			if (sscanf(optarg, "%u/%u", &shard_i, &shard_n) != 2 || shard_n == 0 || shard_i >= shard_n) {
+				fprintf(stderr, PROGRAM ": invalid option: `--shard %s'\n", optarg);
+				exit(EXIT_FAILURE);
+			}
+			break;
+		case OPT_REPORT:
+			report = 1;
+			break;
+		case OPT_HELP:
+			fputs(USAGE, stderr);
+			exit(EXIT_SUCCESS);
+		case OPT_VERSION:
+			fputs(PROGRAM " (MI355X HIP hot path)\n", stderr);
+			exit(EXIT_SUCCESS);
+		default:
+			break;
+		}
+	}
+	time_t rawtime;
+	time(&rawtime);
+	printf("---------- initializing                             : %s", ctime(&rawtime));
+	if (draft.empty()) {
+		fprintf(stderr, PROGRAM ": error: need to specify assembly draft file (-f)\n");
+		die = true;
+	} else {
+		die_unreadable(draft);
+	}
+	if (bf.empty()) {
+		fprintf(stderr, PROGRAM ": error: need to specify the Bloom filter file (-r)\n");
+		die = true;
+	} else {
+		die_unreadable(bf);
+	}
+	if (!bfrep.empty()) {
+		die_unreadable(bfrep);
+	}
+	if (die) {
+		fprintf(stderr, "Try `" PROGRAM " --help' for more information.\n");
+		exit(EXIT_FAILURE);
+	}
+	if (p.snv) {
+		fprintf(stderr, PROGRAM ": error: SNV mode (-s 1) is not available on the HIP path yet.\n");
+		exit(EXIT_FAILURE);
+	}
+
+	ntedit_hip_ctx* ctx = nullptr;
+	if (ntedit_hip_create(gpu, &ctx) != 0) {
+		fprintf(stderr, PROGRAM ": error: no usable HIP device %d (this build has no CPU path).\n", gpu);
+		exit(EXIT_FAILURE);
+	}
+	time(&rawtime);
+	printf("---------- loading Bloom filter from file           : %s\n", ctime(&rawtime));
+	if (ntedit_hip_load_filter_file(ctx, NTEDIT_FILTER_PRIMARY, bf.c_str()) != 0) {
+		fprintf(stderr, PROGRAM ": error: Bloom filter file supplied (-r) is incorrect. (%s)\n", ntedit_hip_last_error(ctx));
+		exit(EXIT_FAILURE);
+	}
+	uint32_t k = 0, h = 0;
+	uint64_t nbytes = 0;
+	int counting = 0;
+	ntedit_hip_filter_info(ctx, NTEDIT_FILTER_PRIMARY, &k, &h, &nbytes, &counting);
+	printf("BLOOM::\tcounting: %s\tsize: %llu\tnumber hash functions: %u\tkmer size: %u\n", counting ? "YES" : "NO",
+	       (unsigned long long)nbytes, h, k);
+	if (counting) {
+		fprintf(stderr, PROGRAM ": error: counting Bloom filters are not available on the HIP path yet.\n");
+		exit(EXIT_FAILURE);
+	}
+	if (p.min_threshold != 1) {
+		// ntedit.cpp:2453-2458
+		fprintf(stderr, PROGRAM ": warning: Bloom filter is not counting, min k-mer presence threshold will be set to 1.\n");
+		p.min_threshold = 1;
+	}
+	time(&rawtime);
+	printf("\n---------- verifying parameters                     : %s", ctime(&rawtime));
+	char warn[1024];
+	ntedit_hip_params_clamp(&p, warn, sizeof warn);
+	if (warn[0]) {
+		fputs(warn, stderr);
+	}
+	if (prefix.empty()) {
+		// ntedit.cpp:2496-2502
+		std::ostringstream o;
+		o << base_name(draft) << "_k" << k << "_z" << p.min_contig_len << "_r" << base_name(bf) << "_i"
+		  << p.max_insertions << "_d" << p.max_deletions << "_m" << p.mode;
+		prefix = o.str();
+	}
+	printf("\nrunning : " PROGRAM " (MI355X HIP hot path)\n -f %s\n -k %u\n -z %u\n -b %s\n -r %s\n -e %s\n -i %u\n -d %u",
+	       base_name(draft).c_str(), k, p.min_contig_len, prefix.c_str(), base_name(bf).c_str(),
+	       base_name(bfrep).c_str(), p.max_insertions, p.max_deletions);
+	if (p.use_ratio) {
+		printf("\n -X %g\n -Y %g", p.missing_ratio, p.edit_ratio);
+	} else {
+		printf("\n -x %g\n -y %g", p.missing_threshold, p.edit_threshold);
+	}
+	printf("\n -j %u\n -m %d\n -s %d\n -l %s\n -a %d\n -t %u\n -v %d\n\n", p.jump, p.mode, p.snv, base_name(vcf).c_str(),
+	       p.mask, nthreads, verbose);
+
+	if (!bfrep.empty()) {
+		time(&rawtime);
+		printf("---------- loading secondary Bloom filter from file : %s\n", ctime(&rawtime));
+		if (ntedit_hip_load_filter_file(ctx, NTEDIT_FILTER_SECONDARY, bfrep.c_str()) != 0) {
+			fprintf(stderr, PROGRAM ": error: secondary Bloom filter file supplied (-e) is incorrect.\n");
+			exit(EXIT_FAILURE);
+		}
+		uint32_t k2 = 0;
+		ntedit_hip_filter_info(ctx, NTEDIT_FILTER_SECONDARY, &k2, nullptr, nullptr, nullptr);
+		if (k2 != k) {
+			fprintf(stderr, PROGRAM ": error: secondary Bloom filter k size (%u) is different than main Bloom filter k size (%u)\n", k2, k);
+			exit(EXIT_FAILURE);
+		}
+	}
+	if (ntedit_hip_set_params(ctx, &p) != 0) {
+		fprintf(stderr, PROGRAM ": error: %s\n", ntedit_hip_last_error(ctx));
+		exit(EXIT_FAILURE);
+	}
+
+	time(&rawtime);
+	printf("---------- reading/processing input sequence        : %s", ctime(&rawtime));
+	const std::string fa_path = prefix + "_edited.fa", tsv_path = prefix + "_changes.tsv",
+	                  vcf_path = prefix + "_variants.vcf";
+	{
+		FILE* f = fopen(fa_path.c_str(), "wb");
+		if (!f) {
+			fprintf(stderr, PROGRAM ": error: cannot write `%s'\n", fa_path.c_str());
+			exit(EXIT_FAILURE);
+		}
+		fclose(f);
+	}
+	if (ntedit_hip_write_tsv_header(tsv_path.c_str(), k, p.jump, counting) != 0) {
+		fprintf(stderr, PROGRAM ": error: cannot write `%s'\n", tsv_path.c_str());
+		exit(EXIT_FAILURE);
+	}
+	if (FILE* v = fopen(vcf_path.c_str(), "wb")) {
+		// ntedit.cpp:2192-2211 (header only; records are outside this path)
+		time_t now = time(nullptr);
+		tm* ltm = localtime(&now);
+		fprintf(v, "##fileformat=VCFv4.2\n##fileDate=%04d%02d%02d\n##source=" PROGRAM "\n##reference=file:%s\n",
+		        1900 + ltm->tm_year, 1 + ltm->tm_mon, ltm->tm_mday, draft.c_str());
+		fputs("##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n", v);
+		fputs("##INFO=<ID=AD,Number=2,Type=Integer,Description=\"Kmer Depth\">\n", v);
+		fputs("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tINTEGRATION\n", v);
+		fclose(v);
+	}
+
+	nte_host::FastaReader reader(draft.c_str());
+	if (!reader.ok()) {
+		fprintf(stderr, PROGRAM ": error: `%s': cannot open\n", draft.c_str());
+		exit(EXIT_FAILURE);
+	}
+	Batch b;
+	std::string hdr, seq;
+	unsigned long long n_contigs = 0, total_bases = 0;
+	double ms_gpu = 0, ms_screen = 0;
+	ntedit_hip_stats tot;
+	memset(&tot, 0, sizeof tot);
+	auto t0 = std::chrono::steady_clock::now();
+	auto flush = [&]() {
+		if (b.names.empty()) {
+			return;
+		}
+		ntedit_hip_result* res = nullptr;
+		int rc = ntedit_hip_polish_batch(ctx, b.blob.data(), b.blob.size(), b.offs.data(), b.lens.data(),
+		                                 (uint32_t)b.names.size(), 0, &res);
+		if (rc != 0) {
+			fprintf(stderr, PROGRAM ": error: %s\n", ntedit_hip_last_error(ctx));
+			exit(EXIT_FAILURE);
+		}
+		std::vector<const char*> names(b.names.size());
+		for (size_t i = 0; i < b.names.size(); i++) {
+			names[i] = b.names[i].c_str();
+		}
+		rc = ntedit_hip_write_outputs(res, b.blob.data(), b.offs.data(), b.lens.data(), names.data(),
+		                              (uint32_t)names.size(), fa_path.c_str(), tsv_path.c_str(), 1);
+		if (rc != 0) {
+			fprintf(stderr, PROGRAM ": error: cannot write outputs\n");
+			exit(EXIT_FAILURE);
+		}
+		ntedit_hip_stats st;
+		ntedit_hip_result_stats(res, &st);
+		ms_gpu += st.ms_total;
+		ms_screen += st.ms_screen;
+		tot.events += st.events;
+		tot.events_applied += st.events_applied;
+		tot.absent_kmers += st.absent_kmers;
+		tot.substitutions += st.substitutions;
+		tot.insertions += st.insertions;
+		tot.deletions += st.deletions;
+		ntedit_hip_result_free(res);
+		b.clear();
+	};
+	unsigned long long idx = 0;
+	while (reader.next(hdr, seq)) {
+		n_contigs++;
+		// strings holding an embedded NUL end there in the reference (contigSeq = seq->seq.s)
+		size_t z = seq.find('\0');
+		if (z != std::string::npos) {
+			seq.resize(z);
+		}
+		if (seq.size() >= p.min_contig_len) { // ntedit.cpp:2242
+			if (shard_n == 1 || (idx % shard_n) == shard_i) {
+				if (seq.size() > 0xFFFFFFF0ull) {
+					fprintf(stderr, PROGRAM ": error: contig longer than 2^32 bases\n");
+					exit(EXIT_FAILURE);
+				}
+				if (!b.names.empty() && b.blob.size() + seq.size() + 1 > batch_bases) {
+					flush();
+				}
+				b.offs.push_back(b.blob.size());
+				b.lens.push_back((uint32_t)seq.size());
+				b.names.push_back(hdr);
+				b.blob.append(seq);
+				b.blob.push_back('\n');
+				total_bases += seq.size();
+			}
+			idx++;
+		}
+		if (n_contigs % 1000000 == 0) {
+			printf("Processed %llu\n", n_contigs);
+		}
+	}
+	flush();
+	auto t1 = std::chrono::steady_clock::now();
+	time(&rawtime);
+	printf("---------- process complete                         : %s", ctime(&rawtime));
+	if (report) {
+		double s = std::chrono::duration<double>(t1 - t0).count();
+		printf("{\"bases\": %llu, \"seconds\": %.6f, \"gpu_ms\": %.3f, \"screen_ms\": %.3f, \"events\": %llu, "
+		       "\"events_applied\": %llu, \"absent_kmers\": %llu, \"substitutions\": %llu, \"insertions\": %llu, "
+		       "\"deletions\": %llu}\n",
+		       total_bases, s, ms_gpu, ms_screen, (unsigned long long)tot.events,
+		       (unsigned long long)tot.events_applied, (unsigned long long)tot.absent_kmers,
+		       (unsigned long long)tot.substitutions, (unsigned long long)tot.insertions,
+		       (unsigned long long)tot.deletions);
+	}
+	ntedit_hip_destroy(ctx);
+	return 0;
+}

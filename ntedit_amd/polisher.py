@@ -1,0 +1,203 @@
+"""Host-side mirror of the reference's per-contig polishing call.
+
+The reference exposes its hot path as
+    kmerizeAndCorrect(hdr, seq, len, bloom, bloomrep, dfout, rfout, vfout, clinvar)
+(ntedit.cpp:1747) driven by readAndCorrect (ntedit.cpp:2154).  `Polisher`
+keeps that shape: load the filter(s) once, set the opt:: parameters, then hand
+it batches of contigs; it returns / writes `_edited.fa` and `_changes.tsv`.
+All compute happens in libntedit_hip.so on the GPU.
+"""
+import ctypes
+import numpy as np
+
+from . import _lib
+from ._lib import NtEditHipError, Params, Stats
+
+PRIMARY, SECONDARY = 0, 1
+
+
+def default_params(**kw):
+    lib = _lib.load()
+    p = Params()
+    lib.ntedit_hip_params_default(ctypes.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def pack_batch(records, min_contig_len=0):
+    """records: iterable of (header_bytes, sequence_bytes).  Returns the batch layout of
+    include/ntedit_hip.h: (blob, offsets u64, lens u32, names) with one '\\n' behind every contig.
+    Contigs shorter than min_contig_len are dropped (ntedit.cpp:2242)."""
+    names, offs, lens, parts = [], [], [], []
+    pos = 0
+    for name, seq in records:
+        if len(seq) < min_contig_len:
+            continue
+        names.append(bytes(name))
+        offs.append(pos)
+        lens.append(len(seq))
+        parts.append(bytes(seq))
+        parts.append(b"\n")
+        pos += len(seq) + 1
+    return b"".join(parts), np.array(offs, dtype=np.uint64), np.array(lens, dtype=np.uint32), names
+
+
+class Result:
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+
+    def stats(self):
+        s = Stats()
+        self._lib.ntedit_hip_result_stats(self._h, ctypes.byref(s))
+        return s
+
+    def write(self, blob, offsets, lens, names, fa_path, tsv_path, append=False):
+        n = len(names)
+        arr = (ctypes.c_char_p * max(n, 1))(*names)
+        buf = blob if isinstance(blob, (bytes, bytearray)) else bytes(blob)
+        rc = self._lib.ntedit_hip_write_outputs(
+            self._h, ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p),
+            offsets.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), arr, n,
+            fa_path.encode() if fa_path else None, tsv_path.encode() if tsv_path else None, 1 if append else 0)
+        if rc:
+            raise NtEditHipError("write_outputs failed (%d)" % rc)
+
+    def free(self):
+        if self._h:
+            self._lib.ntedit_hip_result_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.free()
+
+
+class Polisher:
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self._lib.ntedit_hip_create(device, ctypes.byref(h))
+        if rc:
+            raise NtEditHipError("ntedit_hip_create(device=%d) failed (%d): no usable HIP device" % (device, rc))
+        self._h = h
+        self.params = default_params()
+
+    def _check(self, rc, what):
+        if rc:
+            msg = self._lib.ntedit_hip_last_error(self._h)
+            raise NtEditHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def close(self):
+        if self._h:
+            self._lib.ntedit_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- filters
+    def load_filter_file(self, path, slot=PRIMARY):
+        self._check(self._lib.ntedit_hip_load_filter_file(self._h, slot, path.encode()), "load_filter_file")
+
+    def set_filter(self, bits, hash_num, k, slot=PRIMARY, counting=False):
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        self._check(self._lib.ntedit_hip_set_filter(self._h, slot, bits.ctypes.data_as(ctypes.c_void_p),
+                                                    bits.size, hash_num, k, int(counting)), "set_filter")
+
+    def set_filter_device(self, device_ptr, nbytes, hash_num, k, slot=PRIMARY, counting=False):
+        self._check(self._lib.ntedit_hip_set_filter_device(self._h, slot, ctypes.c_void_p(device_ptr), nbytes,
+                                                           hash_num, k, int(counting)), "set_filter_device")
+
+    def filter_alloc(self, nbytes, hash_num, k, slot=PRIMARY):
+        self._check(self._lib.ntedit_hip_filter_alloc(self._h, slot, nbytes, hash_num, k), "filter_alloc")
+
+    def filter_insert(self, bases, slot=PRIMARY, device_ptr=None, n=None):
+        if device_ptr is not None:
+            rc = self._lib.ntedit_hip_filter_insert(self._h, slot, ctypes.c_void_p(device_ptr), n, 1)
+        else:
+            rc = self._lib.ntedit_hip_filter_insert(self._h, slot, ctypes.cast(ctypes.c_char_p(bases), ctypes.c_void_p),
+                                                    len(bases), 0)
+        self._check(rc, "filter_insert")
+
+    def filter_download(self, slot=PRIMARY):
+        k, h, nb, cnt = self.filter_info(slot)
+        out = np.empty(nb, dtype=np.uint8)
+        self._check(self._lib.ntedit_hip_filter_download(self._h, slot, out.ctypes.data_as(ctypes.c_void_p)),
+                    "filter_download")
+        return out
+
+    def filter_save_file(self, path, slot=PRIMARY):
+        self._check(self._lib.ntedit_hip_filter_save_file(self._h, slot, path.encode()), "filter_save_file")
+
+    def filter_info(self, slot=PRIMARY):
+        k, h, nb, cnt = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64(), ctypes.c_int()
+        self._check(self._lib.ntedit_hip_filter_info(self._h, slot, ctypes.byref(k), ctypes.byref(h),
+                                                     ctypes.byref(nb), ctypes.byref(cnt)), "filter_info")
+        return k.value, h.value, nb.value, bool(cnt.value)
+
+    def filter_device_ptr(self, slot=PRIMARY):
+        return self._lib.ntedit_hip_filter_device_ptr(self._h, slot)
+
+    # ---- parameters
+    def set_params(self, params):
+        self.params = params
+        self._check(self._lib.ntedit_hip_set_params(self._h, ctypes.byref(params)), "set_params")
+
+    # ---- hot path
+    def screen(self, blob):
+        """absent bitmap (np.uint64 words) for a host batch"""
+        n = len(blob)
+        out = np.zeros((n + 63) // 64, dtype=np.uint64)
+        self._check(self._lib.ntedit_hip_screen(self._h, ctypes.cast(ctypes.c_char_p(blob), ctypes.c_void_p), n, 0,
+                                                out.ctypes.data_as(ctypes.c_void_p)), "screen")
+        return out
+
+    def screen_device(self, bases_ptr, n, bitmap_ptr):
+        self._check(self._lib.ntedit_hip_screen(self._h, ctypes.c_void_p(bases_ptr), n, 1,
+                                                ctypes.c_void_p(bitmap_ptr)), "screen")
+        return self._lib.ntedit_hip_last_kernel_ms(self._h)
+
+    def polish_batch(self, blob, offsets, lens, device_ptr=None, n=None):
+        res = ctypes.c_void_p()
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        if device_ptr is not None:
+            rc = self._lib.ntedit_hip_polish_batch(self._h, ctypes.c_void_p(device_ptr), n,
+                                                   offsets.ctypes.data_as(ctypes.c_void_p),
+                                                   lens.ctypes.data_as(ctypes.c_void_p), len(lens), 1,
+                                                   ctypes.byref(res))
+        else:
+            rc = self._lib.ntedit_hip_polish_batch(self._h, ctypes.cast(ctypes.c_char_p(blob), ctypes.c_void_p),
+                                                   len(blob), offsets.ctypes.data_as(ctypes.c_void_p),
+                                                   lens.ctypes.data_as(ctypes.c_void_p), len(lens), 0,
+                                                   ctypes.byref(res))
+        self._check(rc, "polish_batch")
+        return Result(self._lib, res)
+
+    def polish_records(self, records, out_prefix):
+        """readAndCorrect at -t 1 for an in-memory list of (header, sequence): writes
+        <prefix>_edited.fa and <prefix>_changes.tsv; returns Stats."""
+        blob, offs, lens, names = pack_batch(records, self.params.min_contig_len)
+        k, h, _, counting = self.filter_info(PRIMARY)
+        tsv = out_prefix + "_changes.tsv"
+        fa = out_prefix + "_edited.fa"
+        rc = self._lib.ntedit_hip_write_tsv_header(tsv.encode(), k, self.params.jump, int(counting))
+        if rc:
+            raise NtEditHipError("cannot write %s" % tsv)
+        open(fa, "wb").close()
+        res = self.polish_batch(blob, offs, lens)
+        res.write(blob, offs, lens, names, fa, tsv, append=True)
+        st = res.stats()
+        res.free()
+        return st
+
+    def gather_bench(self, nbytes, n_probes):
+        pps, ms = ctypes.c_double(), ctypes.c_float()
+        self._check(self._lib.ntedit_hip_gather_bench(self._h, nbytes, n_probes, ctypes.byref(pps), ctypes.byref(ms)),
+                    "gather_bench")
+        return pps.value, ms.value

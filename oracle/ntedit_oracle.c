@@ -1975,3 +1975,24 @@ ora_polish_file(
 	}
 	return 0;
 }
+
+/* flat-argument wrapper for ctypes callers (tests) */
+void
+ora_screen_flat(
+    const char* seq,
+    size_t len,
+    const uint8_t* bf_data,
+    uint64_t bf_bytes,
+    unsigned hash_num,
+    unsigned k,
+    uint64_t* bitmap)
+{
+	ora_bf bf;
+	memset(&bf, 0, sizeof bf);
+	bf.data = (uint8_t*)bf_data;
+	bf.bytes = bf_bytes;
+	bf.bits = bf_bytes * 8;
+	bf.hash_num = hash_num;
+	bf.k = k;
+	ora_screen(seq, len, &bf, bitmap);
+}

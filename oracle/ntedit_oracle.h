@@ -113,6 +113,15 @@ int ora_polish_file(
  * bases and NOT in the filter. */
 void ora_screen(const char* seq, size_t len, const ora_bf* bloom, uint64_t* bitmap);
 
+void ora_screen_flat(
+    const char* seq,
+    size_t len,
+    const uint8_t* bf_data,
+    uint64_t bf_bytes,
+    unsigned hash_num,
+    unsigned k,
+    uint64_t* bitmap);
+
 /* counters for work-profile checks */
 typedef struct
 {

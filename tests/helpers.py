@@ -239,3 +239,86 @@ def mutate(rng, seq, p_sub=1e-3, p_ins=1e-4, p_del=1e-4, max_indel=5):
             out.append(seq[i])
             i += 1
     return bytes(out)
+
+
+def oracle_screen(blob, bf):
+    lib = oracle_lib()
+    out = np.zeros((len(blob) + 63) // 64, dtype=np.uint64)
+    lib.ora_screen_flat(ctypes.c_char_p(blob), ctypes.c_size_t(len(blob)),
+                        bf["data"].ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bf["bytes"]),
+                        ctypes.c_uint(bf["hash_num"]), ctypes.c_uint(bf["k"]),
+                        out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def make_case(tmp, seed, n=60000, p_sub=2e-3, p_ins=3e-4, p_del=3e-4, k=25, hashes=3, bfbytes=1 << 17,
+              contigs=3, flavor=""):
+    """Writes truth.fa / t.bf / draft.fa (+ r.bf when 'sec' in flavor) under tmp.
+    Returns dict(draft=..., bf=..., rep=... or None)."""
+    os.makedirs(tmp, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    truth = [random_genome(rng, n) for _ in range(contigs)]
+    if "rep" in flavor:
+        t = bytearray(truth[0])
+        unit = random_genome(rng, int(rng.integers(1, 7)))
+        pos = int(rng.integers(1000, n - 2000))
+        rep = (unit * 400)[: int(rng.integers(60, 300))]
+        t[pos:pos + len(rep)] = rep
+        truth[0] = bytes(t)
+    write_fasta(os.path.join(tmp, "truth.fa"), [(b"t%d" % i, s) for i, s in enumerate(truth)])
+    mkbf([os.path.join(tmp, "truth.fa")], os.path.join(tmp, "t.bf"), k=k, hashes=hashes, nbytes=bfbytes)
+    draft = []
+    for i, s in enumerate(truth):
+        d = bytearray(mutate(rng, s, p_sub, p_ins, p_del))
+        if "N" in flavor:
+            for _ in range(3):
+                q = int(rng.integers(0, len(d) - 50))
+                d[q:q + int(rng.integers(1, 40))] = b"N"
+        if "lower" in flavor:
+            q = int(rng.integers(0, len(d) - 5000))
+            d[q:q + 3000] = bytes(d[q:q + 3000]).lower()
+        if "iupac" in flavor:
+            for _ in range(20):
+                q = int(rng.integers(0, len(d)))
+                d[q] = b"RYSWKMBDHV"[int(rng.integers(0, 10))]
+        draft.append((b"c%d some comment" % i if i % 2 else b"c%d" % i, bytes(d)))
+    draft.append((b"short", b"ACGT" * 10))
+    write_fasta(os.path.join(tmp, "draft.fa"), draft, width=70)
+    out = {"draft": os.path.join(tmp, "draft.fa"), "bf": os.path.join(tmp, "t.bf"), "rep": None,
+           "truth": os.path.join(tmp, "truth.fa")}
+    if "sec" in flavor:
+        write_fasta(os.path.join(tmp, "rep.fa"), [(b"r", truth[0][1000:1600])])
+        mkbf([os.path.join(tmp, "rep.fa")], os.path.join(tmp, "r.bf"), k=k, hashes=hashes, nbytes=1 << 14)
+        out["rep"] = os.path.join(tmp, "r.bf")
+    return out
+
+
+# (case kwargs, parameter kwargs) pairs shared by the hostsim (CPU) and GPU parity tests
+PARITY_CONFIGS = [
+    (dict(), dict()),
+    (dict(flavor="N"), dict()),
+    (dict(flavor="lower"), dict()),
+    (dict(flavor="iupac"), dict()),
+    (dict(), dict(mode=1)),
+    (dict(), dict(mode=2, max_insertions=2, max_deletions=2)),
+    (dict(), dict(mask=1)),
+    (dict(), dict(use_ratio=1)),
+    (dict(flavor="sec"), dict()),
+    (dict(p_sub=2e-2, p_ins=3e-3, p_del=3e-3), dict()),
+    (dict(flavor="rep", p_ins=2e-3), dict()),
+    (dict(p_sub=1e-2), dict(node_window=164)),
+    (dict(), dict(start_grid=2)),
+    (dict(), dict(start_grid=1024)),
+    (dict(), dict(max_insertions=0, max_deletions=0)),
+    (dict(), dict(max_insertions=1, max_deletions=1)),
+    (dict(k=32), dict(max_deletions=10)),
+    (dict(), dict(jump=1)),
+    (dict(), dict(jump=5)),
+    (dict(bfbytes=1 << 15), dict()),
+    (dict(), dict(edit_threshold=25.0, missing_threshold=25.0)),
+    (dict(), dict(edit_threshold=25.0, missing_threshold=25.0, node_window=170, mode=1)),
+    (dict(flavor="N lower iupac sec rep"), dict(mode=1, mask=1)),
+    (dict(hashes=4, bfbytes=100003 * 8), dict()),
+    (dict(hashes=1, bfbytes=1 << 18), dict()),
+    (dict(hashes=6, bfbytes=(1 << 18) + 8), dict()),
+]

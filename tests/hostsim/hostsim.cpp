@@ -122,6 +122,8 @@ hostsim_polish(
 	std::vector<Node> nodes(p.node_window);
 	std::vector<u32> ov_pos(p.node_window);
 	std::vector<u8> ov_chr(p.node_window);
+	std::vector<u8> prev(p.node_window);
+	std::vector<int16_t> lps(p.node_window);
 	std::vector<u32> ev_first;
 	bool overflow = false;
 
@@ -143,6 +145,8 @@ hostsim_polish(
 		env.nodes = nodes.data();
 		env.ov_pos = ov_pos.data();
 		env.ov_chr = ov_chr.data();
+		env.prev = prev.data();
+		env.lps = lps.data();
 		env.arena = arena.data();
 		env.arena_next = &arena_next;
 		env.arena_chunks = arena_chunks;

@@ -1,0 +1,135 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Bit-exact bar: bitmaps, filter bytes, _edited.fa and _changes.tsv must be
+byte-identical.  Nothing here reads /root/reference."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def polisher():
+    import ntedit_amd
+    p = ntedit_amd.Polisher(0)
+    yield p
+    p.close()
+
+
+def _hip_params(**kw):
+    import ntedit_amd
+    return ntedit_amd.default_params(**kw)
+
+
+def _load_filters(pol, case):
+    pol.load_filter_file(case["bf"], 0)
+    if case["rep"]:
+        pol.load_filter_file(case["rep"], 1)
+
+
+def _fresh(pol_cls=None):
+    import ntedit_amd
+    return ntedit_amd.Polisher(0)
+
+
+@pytest.mark.parametrize("ci", range(len(H.PARITY_CONFIGS)))
+def test_polish_matches_oracle(tmp_path, ci, oracle_build):
+    case_kw, par_kw = H.PARITY_CONFIGS[ci]
+    case = H.make_case(str(tmp_path), 1000 + ci, **case_kw)
+    hp = H.default_params(**par_kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), case["rep"])
+    pol = _fresh()
+    try:
+        _load_filters(pol, case)
+        pol.set_params(_hip_params(**par_kw))
+        st = pol.polish_records(H.read_fasta(case["draft"]), str(tmp_path / "g"))
+    finally:
+        pol.close()
+    assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "g_changes.tsv"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "g_edited.fa"), shallow=False)
+    assert st.events >= st.events_applied
+
+
+@pytest.mark.parametrize("ci", [0, 1, 3, 16, 23, 24, 25])
+def test_screen_bitmap_matches_oracle(tmp_path, ci, polisher, oracle_build):
+    case_kw, _ = H.PARITY_CONFIGS[ci]
+    case = H.make_case(str(tmp_path), 2000 + ci, **case_kw)
+    bf = H.load_bf(case["bf"])
+    blob, offs, lens, names = H.pack_batch(H.read_fasta(case["draft"]))
+    polisher.set_filter(bf["data"], bf["hash_num"], bf["k"])
+    got = polisher.screen(blob)
+    want = H.oracle_screen(blob, bf)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    assert int(np.unpackbits(got.view(np.uint8)).sum()) > 0
+
+
+def test_screen_edge_sizes(tmp_path, polisher, oracle_build):
+    """empty / shorter-than-k / exactly-k / tile-boundary inputs"""
+    rng = np.random.default_rng(7)
+    truth = H.random_genome(rng, 40000)
+    H.write_fasta(str(tmp_path / "t.fa"), [(b"t", truth)])
+    H.mkbf([str(tmp_path / "t.fa")], str(tmp_path / "t.bf"), k=25, hashes=3, nbytes=1 << 16)
+    bf = H.load_bf(str(tmp_path / "t.bf"))
+    polisher.set_filter(bf["data"], bf["hash_num"], bf["k"])
+    draft = H.mutate(rng, truth, 5e-3, 1e-3, 1e-3)
+    for n in (1, 24, 25, 26, 63, 64, 65, 16383, 16384, 16385, 16384 + 24, 16384 + 25, 32768, 39000):
+        blob = draft[:n]
+        got = polisher.screen(blob)
+        want = H.oracle_screen(blob, bf)
+        assert np.array_equal(got, want), n
+
+
+def test_filter_build_matches_oracle(tmp_path, polisher, oracle_build):
+    """GPU filter build (atomicOr) == the oracle's mkbf, byte for byte"""
+    rng = np.random.default_rng(11)
+    seqs = [H.random_genome(rng, 50000), H.random_genome(rng, 777)]
+    s0 = bytearray(seqs[0])
+    s0[100:130] = b"N" * 30
+    s0[5000] = ord("R")
+    s0[6000:6100] = bytes(s0[6000:6100]).lower()
+    seqs[0] = bytes(s0)
+    H.write_fasta(str(tmp_path / "g.fa"), [(b"a", seqs[0]), (b"b", seqs[1])])
+    for k, h, nbytes in ((25, 3, 1 << 16), (31, 4, 100003 * 8), (40, 2, 1 << 15)):
+        H.mkbf([str(tmp_path / "g.fa")], str(tmp_path / "o.bf"), k=k, hashes=h, nbytes=nbytes)
+        want = H.load_bf(str(tmp_path / "o.bf"))
+        polisher.filter_alloc(nbytes, h, k)
+        polisher.filter_insert(seqs[0] + b"\n" + seqs[1] + b"\n")
+        got = polisher.filter_download()
+        assert np.array_equal(got, want["data"]), (k, h, nbytes)
+        polisher.filter_save_file(str(tmp_path / "g.bf"))
+        again = H.load_bf(str(tmp_path / "g.bf"))
+        assert again["k"] == k and again["hash_num"] == h and np.array_equal(again["data"], want["data"])
+
+
+def test_demo_ecoli(tmp_path, oracle_build):
+    """configs[1]: E. coli demo draft, proxy filter resident in HBM, vs the oracle and vs the
+    reference's committed changes.tsv (soft pin, >= 99% of rows)."""
+    import subprocess, sys
+    demo = os.path.join(H.GOLDEN, "demo")
+    draft = os.path.join(demo, "ecoliWithMismatches001Indels0001.fa.gz")
+    ref_tsv = os.path.join(demo, "ecoli_ntedit_k25_changes.tsv")
+    subprocess.run([sys.executable, os.path.join(H.GOLDEN, "recon_demo.py"), draft, ref_tsv,
+                    str(tmp_path / "truth.fa")], check=True)
+    H.mkbf([str(tmp_path / "truth.fa")], str(tmp_path / "p.bf"), k=25, hashes=3, nbytes=1 << 27)
+    hp = H.default_params(max_insertions=4, max_deletions=5)
+    H.run_oracle(draft, str(tmp_path / "p.bf"), hp, str(tmp_path / "o"))
+    pol = _fresh()
+    try:
+        pol.load_filter_file(str(tmp_path / "p.bf"))
+        pol.set_params(_hip_params(max_insertions=4, max_deletions=5))
+        st = pol.polish_records(H.read_fasta(draft), str(tmp_path / "g"))
+    finally:
+        pol.close()
+    assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "g_changes.tsv"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "g_edited.fa"), shallow=False)
+    ref_rows = set(open(ref_tsv).read().splitlines()[1:])
+    got_rows = set(open(str(tmp_path / "g_changes.tsv")).read().splitlines()[1:])
+    assert len(ref_rows & got_rows) >= 0.99 * len(ref_rows)
+    assert open(ref_tsv).readline() == open(str(tmp_path / "g_changes.tsv")).readline()
+    assert st.bases > 4_600_000

@@ -1,0 +1,95 @@
+"""The C-ABI library loads and exports every symbol include/ntedit_hip.h
+declares; without a GPU the product fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import helpers as H
+
+HEADER = os.path.join(H.ROOT, "include", "ntedit_hip.h")
+LIB = os.path.join(H.ROOT, "ntedit_amd", "libntedit_hip.so")
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    if not os.path.exists(LIB):
+        subprocess.run(["make", "-s", "-C", os.path.join(H.ROOT, "ntedit_amd", "csrc")], check=True)
+    return LIB
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ntedit_hip_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(built_lib):
+    lib = ctypes.CDLL(built_lib)
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), s
+    from ntedit_amd import _lib
+    assert sorted(_lib.EXPORTS) == syms
+
+
+def test_params_default_and_clamp(built_lib):
+    import ntedit_amd
+    from ntedit_amd import _lib
+    lib = _lib.load()
+    p = ntedit_amd.default_params()
+    # ntedit.cpp:99-133
+    assert (p.min_contig_len, p.max_insertions, p.max_deletions, p.jump, p.mode) == (100, 5, 5, 3, 0)
+    assert (p.edit_threshold, p.missing_threshold, p.edit_ratio, p.missing_ratio) == (9.0, 5.0, 0.5, 0.5)
+    buf = ctypes.create_string_buffer(1024)
+    p.max_insertions, p.max_deletions = 9, 12
+    lib.ntedit_hip_params_clamp(ctypes.byref(p), buf, 1024)  # ntedit.cpp:2485-2493
+    assert (p.max_insertions, p.max_deletions) == (5, 10)
+    assert b"i parameter too high" in buf.value and b"d parameter too high" in buf.value
+    p.max_insertions, p.max_deletions = 0, 3
+    lib.ntedit_hip_params_clamp(ctypes.byref(p), buf, 1024)  # ntedit.cpp:2478-2483
+    assert (p.max_insertions, p.max_deletions) == (0, 0)
+    p.max_insertions, p.max_deletions = 1, 4
+    lib.ntedit_hip_params_clamp(ctypes.byref(p), buf, 1024)
+    assert (p.max_insertions, p.max_deletions) == (1, 1)
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly(built_lib, tmp_path):
+    import ntedit_amd
+    with pytest.raises(ntedit_amd.NtEditHipError):
+        ntedit_amd.Polisher(0)
+    # the CLI refuses as well (reference convention: message on stderr, EXIT_FAILURE)
+    cli = os.path.join(H.ROOT, "ntedit_amd", "ntedit")
+    if os.path.exists(cli):
+        f = tmp_path / "d.fa"
+        f.write_text(">a\nACGT\n")
+        r = subprocess.run([cli, "-f", str(f), "-r", str(f)], capture_output=True, text=True)
+        assert r.returncode != 0 and "error" in r.stderr
+
+
+def test_cli_argument_errors(built_lib, tmp_path):
+    cli = os.path.join(H.ROOT, "ntedit_amd", "ntedit")
+    if not os.path.exists(cli):
+        pytest.skip("CLI not built")
+    r = subprocess.run([cli], capture_output=True, text=True)
+    assert r.returncode != 0
+    assert "need to specify assembly draft file (-f)" in r.stderr  # ntedit.cpp:2380
+    assert "need to specify the Bloom filter file (-r)" in r.stderr  # ntedit.cpp:2389
+    r = subprocess.run([cli, "-f", "/nonexistent.fa", "-r", "x"], capture_output=True, text=True)
+    assert r.returncode != 0 and "/nonexistent.fa" in r.stderr
+    r = subprocess.run([cli, "-z", "abc"], capture_output=True, text=True)
+    assert r.returncode != 0 and "invalid option" in r.stderr  # ntedit.cpp:2360-2363
+    r = subprocess.run([cli, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "-f," in r.stderr

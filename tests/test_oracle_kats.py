@@ -1,0 +1,127 @@
+"""Known-answer / self-consistency tests of the CPU oracle's primitives
+(roll == re-seed, canonical(kmer) == canonical(revcomp(kmer)),
+changelast == re-seed) and of the product's host+device hashing header against
+the oracle (via the test-only host build)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+COMP = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+
+
+def revcomp(s):
+    return s.translate(COMP)[::-1]
+
+
+def canon(lib, s, k):
+    return (lib.ora_base_forward_hash(s, k) + lib.ora_base_reverse_hash(s, k)) & (2**64 - 1)
+
+
+def test_split_rotate_is_a_bijection_with_period_1023(oracle_build):
+    lib = H.oracle_lib()
+    rng = np.random.default_rng(1)
+    for x in [int(v) for v in rng.integers(0, 2**63, size=20, dtype=np.int64)] + [1, 2**32, 2**33, 2**63, 2**64 - 1]:
+        assert lib.ora_sror(lib.ora_srol(x)) == x
+        assert lib.ora_srol_n(x, 1) == lib.ora_srol(x)
+        assert lib.ora_srol_n(x, 33 * 31) == x
+        y = x
+        for _ in range(7):
+            y = lib.ora_srol(y)
+        assert lib.ora_srol_n(x, 7) == y
+        # the two halves never mix: bit count of each half is invariant
+        lo, hi = x & (2**33 - 1), x >> 33
+        y = lib.ora_srol_n(x, 11)
+        assert bin(y & (2**33 - 1)).count("1") == bin(lo).count("1")
+        assert bin(y >> 33).count("1") == bin(hi).count("1")
+
+
+@pytest.mark.parametrize("k", [12, 25, 31, 32, 33, 40, 64, 100])
+def test_roll_equals_reseed_and_strand_symmetry(k, oracle_build):
+    lib = H.oracle_lib()
+    rng = np.random.default_rng(k)
+    s = H.random_genome(rng, 400)
+    fh = lib.ora_base_forward_hash(s[:k], k)
+    rh = lib.ora_base_reverse_hash(s[:k], k)
+    for i in range(1, 400 - k):
+        fh = lib.ora_next_forward_hash(fh, k, s[i - 1], s[i + k - 1])
+        rh = lib.ora_next_reverse_hash(rh, k, s[i - 1], s[i + k - 1])
+        km = s[i:i + k]
+        assert fh == lib.ora_base_forward_hash(km, k)
+        assert rh == lib.ora_base_reverse_hash(km, k)
+        # forward hash of the reverse complement is the reverse hash, so fh+rh is strand-neutral
+        assert lib.ora_base_forward_hash(revcomp(km), k) == rh
+        assert canon(lib, km, k) == canon(lib, revcomp(km), k)
+    # case-insensitive
+    assert canon(lib, s[:k].lower(), k) == canon(lib, s[:k], k)
+
+
+def test_published_seed_constants(oracle_build):
+    """ntHash2's four seeds and the multi-hash constants (the only hard numbers
+    this path has; btllib itself is unavailable => 'parity unpinned')."""
+    lib = H.oracle_lib()
+    lib.ora_seed.restype = ctypes.c_uint64
+    lib.ora_seed.argtypes = [ctypes.c_ubyte]
+    assert lib.ora_seed(ord("A")) == 0x3C8BFBB395C60474
+    assert lib.ora_seed(ord("C")) == 0x3193C18562A02B4C
+    assert lib.ora_seed(ord("G")) == 0x20323ED082572324
+    assert lib.ora_seed(ord("T")) == 0x295549F54BE24456
+    assert lib.ora_seed(ord("N")) == 0
+    for c, comp in zip(b"ACGT", b"TGCA"):
+        assert lib.ora_seed(c & 7) == lib.ora_seed(comp)
+    hv = (ctypes.c_uint64 * 3)()
+    lib.ora_extend_hashes.argtypes = [ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint64)]
+    lib.ora_extend_hashes(0x0123456789ABCDEF, 25, 3, hv)
+    base = 0x0123456789ABCDEF
+    for i in (1, 2):
+        t = (base * (i ^ ((25 * 0x90B45D39FB6DA1FA) & (2**64 - 1)))) & (2**64 - 1)
+        assert hv[i] == t ^ (t >> 27)
+    assert hv[0] == base
+
+
+def test_filter_roundtrip_and_membership(tmp_path, oracle_build):
+    rng = np.random.default_rng(3)
+    g = H.random_genome(rng, 20000)
+    H.write_fasta(str(tmp_path / "g.fa"), [(b"g", g)], width=60)
+    for nbytes in (1 << 16, 100003 * 8):
+        H.mkbf([str(tmp_path / "g.fa")], str(tmp_path / "g.bf"), k=25, hashes=3, nbytes=nbytes)
+        bf = H.load_bf(str(tmp_path / "g.bf"))
+        assert bf["k"] == 25 and bf["hash_num"] == 3 and bf["bytes"] == nbytes and not bf["counting"]
+        # every k-mer of g is present; both strands
+        bm = H.oracle_screen(g, bf)
+        assert not bm.any()
+        bm = H.oracle_screen(revcomp(g), bf)
+        assert not bm.any()
+        # a random sequence is mostly absent
+        other = H.random_genome(rng, 20000)
+        frac = np.unpackbits(H.oracle_screen(other, bf).view(np.uint8)).sum() / (20000 - 24)
+        assert frac > 0.8
+
+
+def test_host_device_header_matches_oracle_screen(tmp_path, oracle_build):
+    """nte_common.h (the product's hashing + probe arithmetic, host build) == oracle,
+    including IUPAC / N / lowercase / separators and a non-power-of-two filter."""
+    sim = H.hostsim_lib()
+    rng = np.random.default_rng(5)
+    g = H.random_genome(rng, 30000)
+    H.write_fasta(str(tmp_path / "g.fa"), [(b"g", g)])
+    for k, h, nbytes in ((25, 3, 1 << 15), (40, 4, 50021 * 8), (13, 1, 1 << 12)):
+        H.mkbf([str(tmp_path / "g.fa")], str(tmp_path / "g.bf"), k=k, hashes=h, nbytes=nbytes)
+        bf = H.load_bf(str(tmp_path / "g.bf"))
+        d = bytearray(H.mutate(rng, g, 5e-3, 1e-3, 1e-3))
+        d[1000:1030] = b"N" * 30
+        d[2000] = ord("\n")
+        for i, c in enumerate(b"RYSWKMBDHVUXn-*"):
+            d[3000 + 40 * i] = c
+        d[5000:5200] = bytes(d[5000:5200]).lower()
+        blob = bytes(d)
+        want = H.oracle_screen(blob, bf)
+        got = np.zeros_like(want)
+        rc = sim.hostsim_screen(ctypes.c_char_p(blob), ctypes.c_uint64(len(blob)),
+                                bf["data"].ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bf["bytes"]),
+                                ctypes.c_uint32(h), ctypes.c_uint32(k), got.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        assert np.array_equal(got, want)

@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py -- polished Mbases/s of the ntEdit hot path on MI355X.
+
+One "step" = one pass of the hot path (screen -> event extraction -> event
+machine -> edit records back in host memory) over one batch of synthetic draft
+that is already resident in HBM.  Workload at N=1 (BASELINE.json: the config
+the metric is quoted on): synthetic 3 Gbp draft (0.1% substitutions, 0.01%
+indels), k=25, 4 GiB Bloom filter with h=3 built from the truth genome.
+N>1: one process per GPU; every rank polishes its own 3 Gbp draft (same truth
+genome, rank-specific mutations) against an identical filter that rank 0 builds
+and broadcasts once over RCCL (the path's single collective, untimed set-up);
+no communication inside the timed region -> weak scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
+objects: "roofline" (screening kernel, HBM-bound; algorithmic bytes = 4.125 B
+per screened base at h=3) and "cpu_baseline" (the C oracle timed on a bounded
+sample of the same draft + filter on the host; N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bases", type=float, default=3.0e9, help="draft bases per GPU")
+    ap.add_argument("--filter-bytes", type=int, default=1 << 32)
+    ap.add_argument("--k", type=int, default=25)
+    ap.add_argument("--hashes", type=int, default=3)
+    ap.add_argument("--cpu-sample-bases", type=float, default=30e6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--screen-only", action="store_true", help="time only the screening kernel (profiling aid)")
+    return ap.parse_args()
+
+
+def cpu_baseline(job, pol, args):
+    """The oracle ("port"), 1 thread, on the first contigs of the same draft (~cpu-sample-bases),
+    same filter (downloaded from HBM).  Reported, not targeted."""
+    import numpy as np
+    import torch
+    import helpers as H
+
+    H.build_oracle()
+    lib = ctypes.CDLL(os.path.join(H.ORACLE_BUILD, "libntedit_oracle.so"))
+    lib.ora_polish_batch_flat.restype = ctypes.c_uint64
+
+    class OraParams(ctypes.Structure):
+        _fields_ = [("k", ctypes.c_uint), ("h", ctypes.c_uint), ("jump", ctypes.c_uint),
+                    ("min_contig_len", ctypes.c_uint), ("max_insertions", ctypes.c_uint),
+                    ("max_deletions", ctypes.c_uint), ("edit_threshold", ctypes.c_float),
+                    ("missing_threshold", ctypes.c_float), ("edit_ratio", ctypes.c_float),
+                    ("missing_ratio", ctypes.c_float), ("use_ratio", ctypes.c_int),
+                    ("insertion_cap", ctypes.c_uint), ("mode", ctypes.c_int), ("snv", ctypes.c_int),
+                    ("mask", ctypes.c_int), ("secbf", ctypes.c_int), ("min_threshold", ctypes.c_uint),
+                    ("max_threshold", ctypes.c_uint)]
+
+    p = OraParams()
+    lib.ora_params_default(ctypes.byref(p))
+    # pick whole contigs, shortest first in input order, until the sample is filled
+    want = int(args.cpu_sample_bases)
+    idx, total = [], 0
+    for i in np.argsort(job.lens, kind="stable"):
+        if total >= want:
+            break
+        if total + int(job.lens[i]) > 2 * want and total > 0:
+            continue
+        idx.append(int(i))
+        total += int(job.lens[i])
+    idx.sort()
+    parts, offs, lens, pos = [], [], [], 0
+    for i in idx:
+        o, l = int(job.offsets[i]), int(job.lens[i])
+        parts.append(job.batch[o:o + l + 1].cpu().numpy().tobytes())
+        offs.append(pos)
+        lens.append(l)
+        pos += l + 1
+    blob = b"".join(parts)
+    offs = np.array(offs, dtype=np.uint64)
+    lens = np.array(lens, dtype=np.uint32)
+    bits = pol.filter_download(0)
+    k, h, nbytes, _ = pol.filter_info(0)
+    t0 = time.perf_counter()
+    done = lib.ora_polish_batch_flat(
+        ctypes.c_char_p(blob), offs.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), None,
+        ctypes.c_uint32(len(lens)), bits.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(nbytes),
+        ctypes.c_uint(h), ctypes.c_uint(k), None, ctypes.c_uint64(0), ctypes.c_uint(0), ctypes.byref(p), None, None)
+    dt = time.perf_counter() - t0
+    return {"value": done / dt / 1e6, "unit": "Mbases/s", "cores": 1, "kind": "port",
+            "sample": "%d contigs / %.1f Mbases of the same draft, same %d-byte filter, 1 thread, %.1f s" %
+                      (len(lens), done / 1e6, nbytes, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import ntedit_amd
+    from ntedit_amd import dist as ndist
+    from ntedit_amd.synth import SyntheticJob
+
+    rank, world, local = ndist.env_rank()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    ndist.init_process_group("nccl")
+    dev = torch.device("cuda", local)
+
+    pol = ntedit_amd.Polisher(local)
+    pol.set_params(ntedit_amd.default_params())
+    t_setup = time.perf_counter()
+    # same truth genome on every rank; rank 0 builds the filter and broadcasts it (RCCL)
+    job = SyntheticJob(pol, args.bases, k=args.k, hash_num=args.hashes, filter_bytes=args.filter_bytes,
+                       seed=20251031, draft_seed=20251032 + rank, device=dev, build_filter=(rank == 0 or world == 1))
+    if world > 1:
+        ndist.broadcast_filter(pol, src=0)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    def step():
+        if args.screen_only:
+            ms = pol.screen_device(job.device_ptr, job.n_bytes, bitmap.data_ptr())
+            return None, ms
+        res = pol.polish_batch(None, job.offsets, job.lens, device_ptr=job.device_ptr, n=job.n_bytes)
+        st = res.stats()
+        res.free()
+        return st, st.ms_screen
+
+    if args.screen_only:
+        bitmap = torch.zeros((job.n_bytes + 63) // 64 + 1, dtype=torch.int64, device=dev)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    screen_ms, machine_ms, extract_ms, last = [], [], [], None
+    for _ in range(args.steps):
+        st, ms = step()
+        screen_ms.append(ms)
+        if st is not None:
+            machine_ms.append(st.ms_machine)
+            extract_ms.append(st.ms_extract)
+            last = st
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        nb = torch.tensor([job.n_bases], dtype=torch.int64, device=dev)
+        dist.all_reduce(nb, op=dist.ReduceOp.SUM)
+        total_bases = int(nb.item())
+    else:
+        total_bases = job.n_bases
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_bases * args.steps / elapsed / 1e6
+        avg_screen = sum(screen_ms) / len(screen_ms)
+        algo_bytes = (args.hashes + 1 + 0.125) * job.n_bytes  # h filter bytes + 1 draft byte + 1/8 bitmap byte
+        achieved = algo_bytes / (avg_screen * 1e-3) / 1e9
+        out = {
+            "metric": "polished Mbases/s",
+            "value": round(value, 2),
+            "unit": "Mbases/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": "synthetic %.2f Gbp draft per GPU (%d contigs, 0.1%% sub + 0.01%% indel, 1 kbp N-run / 10 Mbp), "
+                            "k=%d, %d-byte Bloom filter h=%d, %s" %
+                            (job.n_bases / 1e9, len(job.lens), args.k, args.filter_bytes, args.hashes,
+                             "screen kernel only" if args.screen_only else
+                             "screen + event extraction + event machine + edit records to host"),
+                "bases_per_gpu": job.n_bases,
+                "parallelism": "contig shards, %d rank(s), filter broadcast once (untimed)" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_screen",
+                "achieved": round(achieved, 2),
+                "peak": 8000.0,
+                "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 5),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": int(algo_bytes),
+                "avg_launch_ms": round(avg_screen, 3),
+                "probes_per_s": round(args.hashes * job.n_bytes / (avg_screen * 1e-3), 0),
+            },
+            "setup_s": round(t_setup, 1),
+        }
+        if last is not None:
+            out["phases_ms"] = {"screen": round(avg_screen, 3),
+                                "extract": round(sum(extract_ms) / len(extract_ms), 3),
+                                "machine": round(sum(machine_ms) / len(machine_ms), 3)}
+            out["events"] = {"absent_kmers": int(last.absent_kmers), "event_threads": int(last.events)}
+        if not args.no_gather:
+            try:
+                pps, gms = pol.gather_bench(args.filter_bytes if args.filter_bytes & (args.filter_bytes - 1) == 0
+                                            else 1 << 32, 4_000_000_000)
+                out["roofline"]["random_gather_probes_per_s"] = round(pps, 0)
+                out["roofline"]["frac_of_random_gather"] = round(out["roofline"]["probes_per_s"] / pps, 4)
+            except Exception as e:  # pragma: no cover
+                out["roofline"]["random_gather_error"] = str(e)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(job, pol, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    pol.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+"""Multi-GPU layout of the hot path: one process per GPU (torch.distributed,
+backend "nccl" = RCCL on ROCm, "gloo" on CPU for the tests).
+
+The path shards embarrassingly: contigs are independent (ntedit.cpp:2213-2252
+hands one contig to each OpenMP thread), so the only data-path collective is
+ONE broadcast of the Bloom filter bit array from rank 0 at start-up; after that
+ranks never talk until the host-side gather of per-shard outputs, which is
+concatenated back in input order (= the reference at -t 1)."""
+import os
+
+import numpy as np
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_process_group(backend=None):
+    import torch
+    import torch.distributed as dist
+    rank, world, local = env_rank()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_contigs(lens, world, min_len=0):
+    """Greedy LPT partition of contig indices by BASES (not by count): returns a list of
+    index arrays, one per rank, each in input order.  Deterministic on every rank."""
+    lens = np.asarray(lens, dtype=np.int64)
+    idx = [i for i in range(len(lens)) if lens[i] >= min_len]
+    order = sorted(idx, key=lambda i: (-int(lens[i]), i))
+    load = [0] * world
+    parts = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        parts[r].append(i)
+        load[r] += int(lens[i])
+    return [np.array(sorted(p), dtype=np.int64) for p in parts]
+
+
+def broadcast_filter_tensor(t, src=0):
+    """The path's single collective: broadcast the filter bit array (uint8 tensor, on the
+    GPU for nccl/RCCL, on the CPU for gloo) from rank `src` to every rank."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=src)
+    return t
+
+
+def broadcast_filter(polisher, meta=None, src=0):
+    """Rank `src` holds the filter in its Polisher; afterwards every rank's Polisher
+    points at an identical HBM copy.  meta = (k, hash_num, nbytes) must be known on
+    every rank (it is broadcast as a tiny tensor first)."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    dev = torch.device("cuda", torch.cuda.current_device())
+    hdr = torch.zeros(3, dtype=torch.int64, device=dev)
+    if rank == src:
+        k, h, nbytes, _ = polisher.filter_info(0)
+        hdr[0], hdr[1], hdr[2] = k, h, nbytes
+    broadcast_filter_tensor(hdr, src)
+    k, h, nbytes = int(hdr[0]), int(hdr[1]), int(hdr[2])
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if rank == src:
+        # device-to-device copy of rank src's filter into the collective buffer
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        rc = hip.hipMemcpy(buf.data_ptr(), polisher.filter_device_ptr(0), nbytes, 3)
+        if rc:
+            raise RuntimeError("hipMemcpy D2D failed (%d)" % rc)
+    torch.cuda.synchronize()
+    broadcast_filter_tensor(buf, src)
+    torch.cuda.synchronize()
+    polisher.set_filter_device(buf.data_ptr(), nbytes, h, k)
+    polisher._filter_keepalive = buf
+    return buf
+
+
+def run_sharded(records, polish_fn, out_prefix, min_len, rank, world, barrier=None):
+    """records: [(header, seq)] known on every rank.  polish_fn(sub_records, prefix) writes
+    <prefix>_edited.fa / <prefix>_changes.tsv for its contigs (each file WITHOUT any shared
+    header handling: the TSV starts with the header line).  Rank 0 then gathers the per-rank
+    files into <out_prefix>_* in input order."""
+    lens = [len(s) for _, s in records]
+    parts = shard_contigs(lens, world, min_len)
+    mine = parts[rank]
+    sub = [records[i] for i in mine]
+    shard_prefix = "%s.shard%d" % (out_prefix, rank)
+    polish_fn(sub, shard_prefix)
+    if barrier:
+        barrier()
+    if rank == 0:
+        merge_shards(records, parts, out_prefix, min_len)
+
+
+def _split_fasta_records(path):
+    recs = []
+    with open(path, "rb") as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            s = f.readline()
+            recs.append(h + s)
+    return recs
+
+
+def merge_shards(records, parts, out_prefix, min_len):
+    """Host-side gather: interleave the shard outputs back into input order."""
+    world = len(parts)
+    fa = [_split_fasta_records("%s.shard%d_edited.fa" % (out_prefix, r)) for r in range(world)]
+    tsv_header = None
+    rows = []
+    for r in range(world):
+        with open("%s.shard%d_changes.tsv" % (out_prefix, r), "rb") as f:
+            lines = f.read().split(b"\n")
+        tsv_header = lines[0]
+        rows.append([l for l in lines[1:] if l])
+    owner = {}
+    for r in range(world):
+        for j, i in enumerate(parts[r]):
+            owner[int(i)] = (r, j)
+    # TSV rows of one contig are contiguous in its shard file, keyed by the contig header
+    cursor = [0] * world
+    with open(out_prefix + "_edited.fa", "wb") as ofa, open(out_prefix + "_changes.tsv", "wb") as otsv:
+        otsv.write(tsv_header + b"\n")
+        for i, (hdr, seq) in enumerate(records):
+            if i not in owner:
+                continue
+            r, j = owner[i]
+            ofa.write(fa[r][j])
+            key = bytes(hdr) + b"\t"
+            c = cursor[r]
+            while c < len(rows[r]) and rows[r][c].startswith(key):
+                otsv.write(rows[r][c] + b"\n")
+                c += 1
+            cursor[r] = c
+    for r in range(world):
+        os.remove("%s.shard%d_edited.fa" % (out_prefix, r))
+        os.remove("%s.shard%d_changes.tsv" % (out_prefix, r))

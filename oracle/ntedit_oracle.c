@@ -1996,3 +1996,65 @@ ora_screen_flat(
 	bf.k = k;
 	ora_screen(seq, len, &bf, bitmap);
 }
+
+/* flat-argument batch driver for ctypes callers (tests, bench cpu_baseline):
+ * polishes the contigs of a packed batch (include/ntedit_hip.h layout) at -t 1.
+ * fa_path / tsv_path may be NULL. Returns bases processed. */
+uint64_t
+ora_polish_batch_flat(
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    const uint8_t* bf_data,
+    uint64_t bf_bytes,
+    unsigned hash_num,
+    unsigned k,
+    const uint8_t* rep_data,
+    uint64_t rep_bytes,
+    unsigned rep_hash_num,
+    const ora_params* params,
+    const char* fa_path,
+    const char* tsv_path)
+{
+	ora_bf bf, rep;
+	memset(&bf, 0, sizeof bf);
+	memset(&rep, 0, sizeof rep);
+	bf.data = (uint8_t*)bf_data;
+	bf.bytes = bf_bytes;
+	bf.bits = bf_bytes * 8;
+	bf.hash_num = hash_num;
+	bf.k = k;
+	if (rep_data) {
+		rep.data = (uint8_t*)rep_data;
+		rep.bytes = rep_bytes;
+		rep.bits = rep_bytes * 8;
+		rep.hash_num = rep_hash_num;
+		rep.k = k;
+	}
+	ora_params p = *params;
+	p.secbf = rep_data != NULL;
+	ora_params_finalize(&p, &bf);
+	FILE* fa = fa_path ? fopen(fa_path, "w") : NULL;
+	FILE* tsv = tsv_path ? fopen(tsv_path, "w") : NULL;
+	if (tsv) {
+		ora_write_tsv_header(tsv, &p, &bf);
+	}
+	uint64_t total = 0;
+	for (uint32_t i = 0; i < n_contigs; i++) {
+		char* seq = (char*)malloc((size_t)lens[i] + 1);
+		memcpy(seq, bases + offsets[i], lens[i]);
+		seq[lens[i]] = 0;
+		ora_polish_contig(names ? names[i] : "c", seq, lens[i], &p, &bf, rep_data ? &rep : NULL, fa, tsv);
+		total += lens[i];
+		free(seq);
+	}
+	if (fa) {
+		fclose(fa);
+	}
+	if (tsv) {
+		fclose(tsv);
+	}
+	return total;
+}

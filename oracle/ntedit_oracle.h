@@ -122,6 +122,23 @@ void ora_screen_flat(
     unsigned k,
     uint64_t* bitmap);
 
+uint64_t ora_polish_batch_flat(
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    const uint8_t* bf_data,
+    uint64_t bf_bytes,
+    unsigned hash_num,
+    unsigned k,
+    const uint8_t* rep_data,
+    uint64_t rep_bytes,
+    unsigned rep_hash_num,
+    const ora_params* params,
+    const char* fa_path,
+    const char* tsv_path);
+
 /* counters for work-profile checks */
 typedef struct
 {

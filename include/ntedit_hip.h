@@ -148,6 +148,7 @@ typedef struct ntedit_hip_stats
 	uint64_t bases;          /* bytes screened                               */
 	uint64_t absent_kmers;   /* set bits in the screening bitmap             */
 	uint64_t events;         /* event threads launched                       */
+	uint64_t events_deferred; /* events re-run by the sweep-only second launch */
 	uint64_t events_applied; /* events that survive the serial-order filter  */
 	uint64_t substitutions, insertions, deletions; /* rope/record counts     */
 	float ms_screen;         /* HIP-event time of the screening kernel       */

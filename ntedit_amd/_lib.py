@@ -41,6 +41,7 @@ class Stats(ctypes.Structure):
         ("bases", ctypes.c_uint64),
         ("absent_kmers", ctypes.c_uint64),
         ("events", ctypes.c_uint64),
+        ("events_deferred", ctypes.c_uint64),
         ("events_applied", ctypes.c_uint64),
         ("substitutions", ctypes.c_uint64),
         ("insertions", ctypes.c_uint64),

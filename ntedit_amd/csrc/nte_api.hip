@@ -50,7 +50,7 @@ struct ntedit_hip_ctx
 	std::string err;
 	float last_ms = 0.f;
 	hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters;
+	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters, deferred;
 	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps;
 	DevBuf offs, lens;
 	u32 cu_count = 256;
@@ -307,7 +307,7 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 		}
 	}
 	DevBuf* bufs[] = { &c->seq,      &c->bitmap,   &c->block_counts, &c->block_offsets, &c->events,
-		               &c->first_chunk, &c->arena, &c->counters,     &c->ws_nodes,      &c->ws_ov_pos,
+		               &c->first_chunk, &c->arena, &c->counters, &c->deferred,     &c->ws_nodes,      &c->ws_ov_pos,
 		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps,       &c->offs,          &c->lens };
 	for (DevBuf* b : bufs) {
 		release(*b);
@@ -764,8 +764,15 @@ ntedit_hip_polish_batch(
 			    (rc = ensure(c, c->ws_prev, threads * W)) || (rc = ensure(c, c->ws_lps, threads * W * 2))) {
 				return bail(rc);
 			}
+			if (n_events > 0xFFFFFFF0ull) {
+				return bail(fail(c, NTEDIT_E_OVERFLOW, "more than 2^32 events in one batch"));
+			}
+			if ((rc = ensure(c, c->deferred, n_events * 4))) {
+				return bail(rc);
+			}
 			u32* d_arena_next = (u32*)((char*)c->counters.p + 32);
 			u32* d_status = (u32*)((char*)c->counters.p + 40);
+			u32* d_ndef = (u32*)((char*)c->counters.p + 44);
 			HIP_TRY(c, hipMemsetAsync((char*)c->counters.p + 32, 0, 16, s));
 			MachineArgs a;
 			a.seq = d_seq;
@@ -789,11 +796,30 @@ ntedit_hip_polish_batch(
 			a.arena_chunks = (u32)arena_chunks;
 			a.first_chunk = (u32*)c->first_chunk.p;
 			a.status = d_status;
+			a.defer = 1;
+			a.ev_list = nullptr;
+			a.deferred = (u32*)c->deferred.p;
+			a.n_deferred = d_ndef;
 			HIP_TRY(c, hipEventRecord(c->ev[3], s));
+			// pass 1: every event, indel sweeps postponed
 			hipLaunchKernelGGL(k_machine, dim3((unsigned)blocks), dim3(MACHINE_TPB), 0, s, a);
 			HIP_TRY(c, hipGetLastError());
-			HIP_TRY(c, hipEventRecord(c->ev[4], s));
 			u32 h_tail[4] = { 0, 0, 0, 0 };
+			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, s));
+			HIP_TRY(c, hipStreamSynchronize(s));
+			const u32 n_def = h_tail[3];
+			r->st.events_deferred = n_def;
+			if (n_def > 0 && h_tail[2] == 0) {
+				// pass 2: only the events that need a sweep, so whole waves are busy with sweeps
+				a.defer = 0;
+				a.ev_list = (const u32*)c->deferred.p;
+				a.n_events = n_def;
+				const u64 blocks2 = ((u64)n_def + MACHINE_TPB - 1) / MACHINE_TPB;
+				const u64 b2 = blocks2 < blocks ? blocks2 : blocks;
+				hipLaunchKernelGGL(k_machine, dim3((unsigned)b2), dim3(MACHINE_TPB), 0, s, a);
+				HIP_TRY(c, hipGetLastError());
+			}
+			HIP_TRY(c, hipEventRecord(c->ev[4], s));
 			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, s));
 			HIP_TRY(c, hipStreamSynchronize(s));
 			const u32 used = h_tail[0], status = h_tail[2];

@@ -285,7 +285,8 @@ enum EventFlags : u32
 {
 	EV_TERMINAL = 1,  // ran to the end of the contig
 	EV_OVERFLOW = 2,  // ran out of node window: results invalid (retry with a larger window)
-	EV_ARENA_FULL = 4 // output arena exhausted: results invalid (retry with a larger arena)
+	EV_ARENA_FULL = 4, // output arena exhausted: results invalid (retry with a larger arena)
+	EV_DEFERRED = 8    // needs an indel sweep and the launch asked to postpone those (pass 1)
 };
 
 struct Item

@@ -374,6 +374,12 @@ struct MachineArgs
 	u32 arena_chunks;
 	u32* first_chunk; // per event
 	u32* status;      // OR of EV_OVERFLOW / EV_ARENA_FULL seen
+	// two-pass launch: pass 1 (defer = 1) postpones events that need an indel sweep by
+	// appending their index to `deferred`; pass 2 runs exactly that list (ev_list)
+	u32 defer;
+	const u32* ev_list; // nullptr = all events 0..n_events-1
+	u32* deferred;
+	u32* n_deferred;
 };
 
 constexpr int MACHINE_TPB = 256;
@@ -404,8 +410,10 @@ k_machine(MachineArgs a)
 	env.arena = a.arena;
 	env.arena_next = a.arena_next;
 	env.arena_chunks = a.arena_chunks;
+	env.defer_sweeps = a.defer != 0;
 
-	for (u64 ev = tid; ev < a.n_events; ev += nthreads) {
+	for (u64 it = tid; it < a.n_events; it += nthreads) {
+		const u64 ev = a.ev_list ? a.ev_list[it] : it;
 		const u64 g = a.events[ev];
 		// contig of g: last offset <= g
 		u32 lo = 0, hi = a.n_contigs;
@@ -430,6 +438,8 @@ k_machine(MachineArgs a)
 			fc = m.finish(start, cover_end);
 			if (m.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
 				atomicOr(a.status, m.flags & (EV_OVERFLOW | EV_ARENA_FULL));
+			} else if (m.flags & EV_DEFERRED) {
+				a.deferred[atomicAdd(a.n_deferred, 1u)] = (u32)ev;
 			}
 		}
 		a.first_chunk[ev] = fc;

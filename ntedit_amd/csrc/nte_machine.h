@@ -52,6 +52,8 @@ struct EventEnv
 	Item* arena;
 	u32* arena_next;
 	u32 arena_chunks;
+	// pass 1 of the two-pass launch: stop (and emit nothing) at the first indel sweep
+	bool defer_sweeps;
 };
 
 NTE_HD bool
@@ -1169,6 +1171,13 @@ struct Machine
 				}
 			}
 			if (p.mode == 2 || b.edit_type != 1) {
+				if (e.defer_sweeps && p.ins_tries > 0) {
+					// the candidate sweep is ~100x the cost of everything else an event
+					// does; running it next to 63 cheap lanes would idle the wave, so the
+					// first pass hands such events to a second, sweep-only launch
+					flags |= EV_DEFERRED;
+					return;
+				}
 				if (try_indels(draft_char, sub_base, num_deletions, b)) {
 					if (p.mode == 0 || p.mode == 1) {
 						break;
@@ -1228,7 +1237,7 @@ struct Machine
 				cover_end = e.len;
 				break;
 			}
-			if (flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
+			if (flags & (EV_OVERFLOW | EV_ARENA_FULL | EV_DEFERRED)) {
 				cover_end = e.len;
 				break;
 			}
@@ -1270,7 +1279,7 @@ struct Machine
 		}
 
 		// stream out what is left of the rope (only if an indel touched it)
-		if (rope_touched) {
+		if (rope_touched && !(flags & EV_DEFERRED)) {
 			for (u32 i = nbase; i < nsize; i++) {
 				Node n = nget(i);
 				if (n.type == -1) {
@@ -1285,7 +1294,7 @@ struct Machine
 	NTE_HD u32
 	finish(u32 start, u32 cover_end)
 	{
-		if (flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
+		if (flags & (EV_OVERFLOW | EV_ARENA_FULL | EV_DEFERRED)) {
 			return NONE32;
 		}
 		if (cur_chunk == NONE32) {

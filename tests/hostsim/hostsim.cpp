@@ -150,12 +150,31 @@ hostsim_polish(
 		env.arena = arena.data();
 		env.arena_next = &arena_next;
 		env.arena_chunks = arena_chunks;
+		env.defer_sweeps = getenv("HOSTSIM_TWO_PASS") != nullptr;
 		Machine m(env);
 		u32 start = (u32)(g - offsets[ci]);
 		u32 cover_end = start;
+		unsigned long long t0c = __builtin_ia32_rdtsc();
 		m.run(start, cover_end);
+		unsigned long long dtc = __builtin_ia32_rdtsc() - t0c;
+		if (getenv("HOSTSIM_HIST")) { fprintf(stderr, "EVT %u %u %llu %d\n", start, cover_end, dtc, (int)(m.first_chunk != NONE32)); }
 		if (m.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
 			overflow = true;
+		}
+		if (m.flags & EV_DEFERRED) {
+			// second pass: the same event again, sweeps allowed
+			env.defer_sweeps = false;
+			Machine m2(env);
+			cover_end = start;
+			m2.run(start, cover_end);
+			if (m2.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
+				overflow = true;
+			}
+			u32 fc2 = m2.finish(start, cover_end);
+			if (fc2 != NONE32) {
+				ev_first.push_back(fc2);
+			}
+			continue;
 		}
 		u32 fc = m.finish(start, cover_end);
 		if (getenv("HOSTSIM_DEBUG")) {

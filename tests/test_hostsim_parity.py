@@ -8,8 +8,15 @@ import pytest
 import helpers as H
 
 
+@pytest.mark.parametrize("two_pass", [False, True])
 @pytest.mark.parametrize("ci", range(len(H.PARITY_CONFIGS)))
-def test_hostsim_matches_oracle(tmp_path, ci, oracle_build):
+def test_hostsim_matches_oracle(tmp_path, ci, two_pass, oracle_build, monkeypatch):
+    # two_pass: the launch scheme of the GPU path (events needing an indel sweep are
+    # postponed to a second, sweep-only pass) must not change anything
+    if two_pass:
+        monkeypatch.setenv("HOSTSIM_TWO_PASS", "1")
+    else:
+        monkeypatch.delenv("HOSTSIM_TWO_PASS", raising=False)
     case_kw, par_kw = H.PARITY_CONFIGS[ci]
     case = H.make_case(str(tmp_path), 3000 + ci, **case_kw)
     hp = H.default_params(**par_kw)

@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--screen-only", action="store_true", help="time only the screening kernel (profiling aid)")
+    ap.add_argument("--start-grid", type=int, default=0, help="event start grid override (tuning)")
     return ap.parse_args()
 
 
@@ -120,7 +121,7 @@ def main():
     dev = torch.device("cuda", local)
 
     pol = ntedit_amd.Polisher(local)
-    pol.set_params(ntedit_amd.default_params())
+    pol.set_params(ntedit_amd.default_params(start_grid=args.start_grid))
     t_setup = time.perf_counter()
     # same truth genome on every rank; rank 0 builds the filter and broadcasts it (RCCL)
     job = SyntheticJob(pol, args.bases, k=args.k, hash_num=args.hashes, filter_bytes=args.filter_bytes,
@@ -216,7 +217,8 @@ def main():
             out["phases_ms"] = {"screen": round(avg_screen, 3),
                                 "extract": round(sum(extract_ms) / len(extract_ms), 3),
                                 "machine": round(sum(machine_ms) / len(machine_ms), 3)}
-            out["events"] = {"absent_kmers": int(last.absent_kmers), "event_threads": int(last.events)}
+            out["events"] = {"absent_kmers": int(last.absent_kmers), "event_threads": int(last.events),
+                             "deferred_to_sweep_pass": int(last.events_deferred)}
         if not args.no_gather:
             try:
                 pps, gms = pol.gather_bench(args.filter_bytes if args.filter_bytes & (args.filter_bytes - 1) == 0

@@ -51,7 +51,7 @@ struct ntedit_hip_ctx
 	float last_ms = 0.f;
 	hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters, deferred;
-	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps;
+	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps, ws_win;
 	DevBuf offs, lens;
 	u32 cu_count = 256;
 };
@@ -308,7 +308,7 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 	}
 	DevBuf* bufs[] = { &c->seq,      &c->bitmap,   &c->block_counts, &c->block_offsets, &c->events,
 		               &c->first_chunk, &c->arena, &c->counters, &c->deferred,     &c->ws_nodes,      &c->ws_ov_pos,
-		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps,       &c->offs,          &c->lens };
+		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win,       &c->offs,          &c->lens };
 	for (DevBuf* b : bufs) {
 		release(*b);
 	}
@@ -791,6 +791,16 @@ ntedit_hip_polish_batch(
 			a.ws_ov_chr = (u8*)c->ws_ov_chr.p;
 			a.ws_prev = (u8*)c->ws_prev.p;
 			a.ws_lps = (int16_t*)c->ws_lps.p;
+			a.win_bytes = 2 * c->dp.k + c->dp.max_deletions + 8;
+			a.win_in_lds = (size_t)a.win_bytes * MACHINE_TPB <= 40 * 1024 ? 1 : 0;
+			a.ws_win = nullptr;
+			if (!a.win_in_lds) {
+				if ((rc = ensure(c, c->ws_win, threads * a.win_bytes))) {
+					return bail(rc);
+				}
+				a.ws_win = (u8*)c->ws_win.p;
+			}
+			const size_t dyn_lds = a.win_in_lds ? (size_t)a.win_bytes * MACHINE_TPB : 0;
 			a.arena = (Item*)c->arena.p;
 			a.arena_next = d_arena_next;
 			a.arena_chunks = (u32)arena_chunks;
@@ -802,10 +812,11 @@ ntedit_hip_polish_batch(
 			a.n_deferred = d_ndef;
 			HIP_TRY(c, hipEventRecord(c->ev[3], s));
 			// pass 1: every event, indel sweeps postponed
-			hipLaunchKernelGGL(k_machine, dim3((unsigned)blocks), dim3(MACHINE_TPB), 0, s, a);
+			hipLaunchKernelGGL(k_machine, dim3((unsigned)blocks), dim3(MACHINE_TPB), dyn_lds, s, a);
 			HIP_TRY(c, hipGetLastError());
 			u32 h_tail[4] = { 0, 0, 0, 0 };
 			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, s));
+			HIP_TRY(c, hipEventRecord(c->ev[5], s));
 			HIP_TRY(c, hipStreamSynchronize(s));
 			const u32 n_def = h_tail[3];
 			r->st.events_deferred = n_def;
@@ -816,12 +827,19 @@ ntedit_hip_polish_batch(
 				a.n_events = n_def;
 				const u64 blocks2 = ((u64)n_def + MACHINE_TPB - 1) / MACHINE_TPB;
 				const u64 b2 = blocks2 < blocks ? blocks2 : blocks;
-				hipLaunchKernelGGL(k_machine, dim3((unsigned)b2), dim3(MACHINE_TPB), 0, s, a);
+				hipLaunchKernelGGL(k_machine, dim3((unsigned)b2), dim3(MACHINE_TPB), dyn_lds, s, a);
 				HIP_TRY(c, hipGetLastError());
 			}
 			HIP_TRY(c, hipEventRecord(c->ev[4], s));
 			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, s));
 			HIP_TRY(c, hipStreamSynchronize(s));
+			if (getenv("NTEDIT_HIP_DEBUG")) {
+				float p1 = 0.f, p2 = 0.f;
+				(void)hipEventElapsedTime(&p1, c->ev[3], c->ev[5]);
+				(void)hipEventElapsedTime(&p2, c->ev[5], c->ev[4]);
+				fprintf(stderr, "[ntedit_hip] events %llu deferred %u pass1 %.3f ms pass2 %.3f ms arena chunks %u status %u window %u\n",
+				        (unsigned long long)n_events, n_def, p1, p2, h_tail[0], h_tail[2], c->dp.node_window);
+			}
 			const u32 used = h_tail[0], status = h_tail[2];
 			if (status == 0) {
 				const u64 used_chunks = used < arena_chunks ? used : arena_chunks;

@@ -368,6 +368,9 @@ struct MachineArgs
 	u8* ws_ov_chr;
 	u8* ws_prev;
 	int16_t* ws_lps;
+	u8* ws_win;     // used when the windows do not fit in LDS
+	u32 win_bytes;  // window bytes per thread
+	u32 win_in_lds;
 	// output
 	Item* arena;
 	u32* arena_next;
@@ -388,6 +391,7 @@ __global__ __launch_bounds__(MACHINE_TPB) void
 k_machine(MachineArgs a)
 {
 	__shared__ u64 s_tab[TAB_WORDS];
+	extern __shared__ __attribute__((aligned(16))) u8 s_win[];
 	if (threadIdx.x < TAB_WORDS) {
 		s_tab[threadIdx.x] = a.tabs[threadIdx.x];
 	}
@@ -405,6 +409,15 @@ k_machine(MachineArgs a)
 	env.nodes = a.ws_nodes + tid * W;
 	env.ov_pos = a.ws_ov_pos + tid * W;
 	env.ov_chr = a.ws_ov_chr + tid * W;
+	if (a.win_in_lds) {
+		// interleaved: byte i of thread t at s_win[i * 256 + t] (no bank conflicts when the
+		// lanes of a wave read the same i)
+		env.win = s_win + threadIdx.x;
+		env.win_stride = MACHINE_TPB;
+	} else {
+		env.win = a.ws_win + tid * a.win_bytes;
+		env.win_stride = 1;
+	}
 	env.prev = a.ws_prev + tid * W;
 	env.lps = a.ws_lps + tid * W;
 	env.arena = a.arena;

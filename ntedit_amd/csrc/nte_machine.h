@@ -46,6 +46,8 @@ struct EventEnv
 	Node* nodes;
 	u32* ov_pos;
 	u8* ov_chr;
+	u8* win;       // character-code window of the failing position: k + (k + max_del + 2) bytes
+	u32 win_stride; // distance between consecutive window bytes (1 = private slice, else interleaved)
 	u8* prev;      // scratch for the previous-insertion string (node_window bytes)
 	int16_t* lps;  // scratch for its KMP failure table (node_window entries)
 	// output arena
@@ -105,6 +107,8 @@ struct Machine
 	// output
 	u32 first_chunk, cur_chunk, fill;
 	u32 flags;
+	// window of the failing position (see fill_window)
+	bool win_ok;
 
 	NTE_HD
 	Machine(const EventEnv& env)
@@ -694,10 +698,142 @@ struct Machine
 		return extra + 1;
 	}
 
+	// ------------------------------------------------ window of a failing position
+	// Every candidate evaluated at one failing position (step 2, the <=4
+	// substitutions, the <=341 insertions per index base, the <=10 deletions)
+	// rolls over the SAME characters: O[i], the i-th character leaving at the
+	// head, and I[i], the i-th character entering behind the tail.  They are
+	// collected once (as 4-bit codes) so that a candidate costs ALU + its Bloom
+	// probes instead of a walk over the rope in global memory.  The fast
+	// evaluators below are used only when the next k+max_del+1 rolls all succeed
+	// (never true within k+d of a contig end); otherwise the general rope-walking
+	// code paths, which restate the reference loop by loop, are used.
+	NTE_HD u32
+	win_len_in() const
+	{
+		return p.k + p.max_deletions + 1;
+	}
+
+	NTE_HD u8
+	win_o(u32 i) const
+	{
+		return e.win[(u64)i * e.win_stride];
+	}
+
+	NTE_HD u8
+	win_i(u32 i) const
+	{
+		return e.win[(u64)(p.k + i) * e.win_stride];
+	}
+
+	NTE_HD bool
+	fill_window()
+	{
+		if (!e.win) {
+			return false; // no window storage: always take the general code paths
+		}
+		const u32 K = win_len_in();
+		Node hn = nget(h_node);
+		// clean fast fill: both cursors in one position node that extends far enough
+		if (h_node == t_node && hn.type == 0 && !tmp_on && n_ov == 0 && t_seq_i == h_seq_i + p.k - 1 &&
+		    (u64)t_seq_i + K <= hn.e_pos && h_seq_i >= hn.s_pos) {
+			const u8* s = e.seq + h_seq_i;
+			for (u32 i = 0; i < p.k + K; i++) {
+				// O[0..k) = s[0..k), I[0..K) = s[k..k+K): contiguous in both arrays
+				e.win[(u64)i * e.win_stride] = char_code(s[i]);
+			}
+			return true;
+		}
+		u32 th = h_seq_i, tt = t_seq_i, thn = h_node, ttn = t_node;
+		u8 co = 0, ci = 0;
+		for (u32 i = 0; i < K; i++) {
+			if (th >= e.len || tt >= e.len) {
+				return false;
+			}
+			if (!roll(th, tt, thn, ttn, co, ci)) {
+				return false;
+			}
+			if (i < p.k) {
+				e.win[(u64)i * e.win_stride] = char_code(co);
+			}
+			e.win[(u64)(p.k + i) * e.win_stride] = char_code(ci);
+		}
+		return true;
+	}
+
+	// number of subset positions (kk % jump == 0) in (kk, last]
+	NTE_HD u32
+	probes_left(u32 kk, u32 last) const
+	{
+		if (kk >= last) {
+			return 0;
+		}
+		return last / p.jump - kk / p.jump;
+	}
+
+	// fast form of try_deletion's support count (ntedit.cpp:1479-1519)
+	NTE_HD u32
+	fast_deletion_support(u8 draft_code, u32 num_del) const
+	{
+		HashState ts = hs;
+		hash_changelast(ts, e.tab, draft_code, win_i(num_del - 1));
+		u32 cp = present_solid(ts) ? 1 : 0;
+		const u32 last = p.k - 2;
+		for (u32 kk = 1; kk <= last; kk++) {
+			hash_roll(ts, e.tab, win_o(kk - 1), win_i(num_del + kk - 1));
+			if (kk % p.jump == 0) {
+				if (present_solid(ts)) {
+					cp++;
+				} else if (cp + probes_left(kk, last) < p.thr_edit_del) {
+					return 0; // cannot reach the threshold any more: rejected either way
+				}
+			}
+		}
+		return cp >= p.thr_edit_del ? cp : 0;
+	}
+
+	// fast form of the insertion support count (ntedit.cpp:1600-1645);
+	// ins = inserted bases (m of them, ins[0] = index base)
+	NTE_HD u32
+	fast_insertion_support(u8 draft_code, const u8* ins, u32 m) const
+	{
+		HashState ts = hs;
+		hash_changelast(ts, e.tab, draft_code, char_code(ins[0]));
+		u32 cp = 0;
+		const u32 last = p.k - 2;
+		for (u32 kk = 0; kk <= last; kk++) {
+			u8 in;
+			if (kk + 1 < m) {
+				in = char_code(ins[kk + 1]);
+			} else if (kk + 1 == m) {
+				in = draft_code;
+			} else {
+				in = win_i(kk - m);
+			}
+			hash_roll(ts, e.tab, win_o(kk), in);
+			if (kk % p.jump == 0) {
+				if (present_solid(ts)) {
+					cp++;
+				} else if (cp + probes_left(kk, last) < p.thr_edit) {
+					return 0;
+				}
+			}
+		}
+		return cp;
+	}
+
 	// ntedit.cpp:1451-1545; returns the support (0 = rejected)
 	NTE_HD u32
 	try_deletion(u8 draft_char, u32 num_deletions, u8* deleted, u32& n_deleted)
 	{
+		if (win_ok) {
+			// only the LENGTH of the deleted run is consumed downstream
+			n_deleted = num_deletions;
+			for (u32 i = 0; i < num_deletions; i++) {
+				deleted[i] = 0;
+			}
+			return fast_deletion_support(char_code(draft_char), num_deletions);
+		}
 		HashState ts = hs;
 		u32 th = h_seq_i, tt = t_seq_i, thn = h_node, ttn = t_node;
 		u8 char_out = 0, char_in = 0;
@@ -745,10 +881,13 @@ struct Machine
 			u32 n_ins = insertion_candidate(index_char, i, ins);
 			ins[n_ins++] = draft_char;
 
+			u32 check_present = 0;
+			if (win_ok) {
+				check_present = fast_insertion_support(char_code(draft_char), ins, n_ins - 1);
+			} else {
 			HashState ts = hs;
 			u32 th = h_seq_i, tt = t_seq_i, thn = h_node, ttn = t_node;
 			changelast(ts, draft_char, index_char);
-			u32 check_present = 0;
 			u32 k = 0;
 			// k-mers that end inside the inserted bases
 			for (; k < n_ins - 1 && th < e.len; k++) {
@@ -766,6 +905,7 @@ struct Machine
 						check_present++;
 					}
 				}
+			}
 			}
 			n_ins--; // drop the draft base again
 			if (check_present >= p.thr_edit) {
@@ -1041,6 +1181,25 @@ struct Machine
 		// step 2: confirm on the k/j subset (ntedit.cpp:1826-1858)
 		u32 check_missing = 0;
 		bool do_not_fix = false;
+		win_ok = fill_window();
+		if (win_ok) {
+			const u32 last = p.k - 1;
+			for (u32 k = 0; k <= last; k++) {
+				const u8 in = win_i(k);
+				hash_roll(ts, e.tab, win_o(k), in);
+				if (in == CODE_BAD) {
+					do_not_fix = true;
+					break;
+				}
+				if (k % p.jump == 0) {
+					if (!in_bloom(ts)) {
+						check_missing++;
+					} else if (check_missing + probes_left(k, last) < p.thr_missing) {
+						return; // the confirmation can no longer succeed
+					}
+				}
+			}
+		} else
 		for (u32 k = 0; k < p.k && th < e.len; k++) {
 			if (roll(th, tt, thn, ttn, char_out, char_in)) {
 				roll_hash(ts, char_out, char_in);
@@ -1094,6 +1253,23 @@ struct Machine
 				nset(t_node, m);
 			}
 			u32 check_present = 0;
+			if (win_ok) {
+				// the substituted base is the last one to leave the window
+				tmp_on = false;
+				const u8 sub_code = char_code(sub_base);
+				const u32 last = p.k - 1;
+				for (u32 k = 0; k <= last; k++) {
+					hash_roll(ts, e.tab, k == last ? sub_code : win_o(k), win_i(k));
+					if (k % p.jump == 0) {
+						if (present_solid(ts)) {
+							check_present++;
+						} else if (check_present + probes_left(k, last) < p.thr_edit) {
+							check_present = 0;
+							break;
+						}
+					}
+				}
+			} else
 			for (u32 k = 0; k < p.k && th < e.len && tt < e.len; k++) {
 				if (roll(th, tt, thn, ttn, char_out, char_in)) {
 					roll_hash(ts, char_out, char_in);
@@ -1203,6 +1379,7 @@ struct Machine
 		tmp_pos = 0;
 		tmp_chr = 0;
 		last_sub_pos = -1;
+		win_ok = false;
 		first_chunk = cur_chunk = NONE32;
 		fill = 0;
 		flags = 0;

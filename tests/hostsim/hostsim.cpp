@@ -122,6 +122,7 @@ hostsim_polish(
 	std::vector<Node> nodes(p.node_window);
 	std::vector<u32> ov_pos(p.node_window);
 	std::vector<u8> ov_chr(p.node_window);
+	std::vector<u8> win(2 * p.k + p.max_deletions + 8);
 	std::vector<u8> prev(p.node_window);
 	std::vector<int16_t> lps(p.node_window);
 	std::vector<u32> ev_first;
@@ -145,6 +146,8 @@ hostsim_polish(
 		env.nodes = nodes.data();
 		env.ov_pos = ov_pos.data();
 		env.ov_chr = ov_chr.data();
+		env.win = getenv("HOSTSIM_NO_WINDOW") ? nullptr : win.data();
+		env.win_stride = 1;
 		env.prev = prev.data();
 		env.lps = lps.data();
 		env.arena = arena.data();

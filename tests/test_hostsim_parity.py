@@ -8,9 +8,15 @@ import pytest
 import helpers as H
 
 
-@pytest.mark.parametrize("two_pass", [False, True])
+@pytest.mark.parametrize("two_pass", [False, True, "nowin"])
 @pytest.mark.parametrize("ci", range(len(H.PARITY_CONFIGS)))
 def test_hostsim_matches_oracle(tmp_path, ci, two_pass, oracle_build, monkeypatch):
+    # "nowin": without the per-position character window every candidate is evaluated by
+    # the general rope-walking code (the path taken near contig ends on the GPU)
+    monkeypatch.delenv("HOSTSIM_NO_WINDOW", raising=False)
+    if two_pass == "nowin":
+        monkeypatch.setenv("HOSTSIM_NO_WINDOW", "1")
+        two_pass = False
     # two_pass: the launch scheme of the GPU path (events needing an indel sweep are
     # postponed to a second, sweep-only pass) must not change anything
     if two_pass:

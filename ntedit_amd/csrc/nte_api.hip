@@ -812,7 +812,7 @@ ntedit_hip_polish_batch(
 			a.n_deferred = d_ndef;
 			HIP_TRY(c, hipEventRecord(c->ev[3], s));
 			// pass 1: every event, indel sweeps postponed
-			hipLaunchKernelGGL(k_machine, dim3((unsigned)blocks), dim3(MACHINE_TPB), dyn_lds, s, a);
+			hipLaunchKernelGGL(k_machine<false>, dim3((unsigned)blocks), dim3(MACHINE_TPB), dyn_lds, s, a);
 			HIP_TRY(c, hipGetLastError());
 			u32 h_tail[4] = { 0, 0, 0, 0 };
 			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, s));
@@ -825,9 +825,12 @@ ntedit_hip_polish_batch(
 				a.defer = 0;
 				a.ev_list = (const u32*)c->deferred.p;
 				a.n_events = n_def;
-				const u64 blocks2 = ((u64)n_def + MACHINE_TPB - 1) / MACHINE_TPB;
-				const u64 b2 = blocks2 < blocks ? blocks2 : blocks;
-				hipLaunchKernelGGL(k_machine, dim3((unsigned)b2), dim3(MACHINE_TPB), dyn_lds, s, a);
+				// one wavefront per deferred event, 4 per workgroup; persistent grid
+				const u64 want2 = ((u64)n_def + 3) / 4;
+				const u64 cap2 = (u64)c->cu_count * 8;
+				const u64 b2 = want2 < cap2 ? want2 : cap2;
+				const size_t dyn2 = a.win_in_lds ? (size_t)a.win_bytes * 4 : 0;
+				hipLaunchKernelGGL(k_machine<true>, dim3((unsigned)b2), dim3(MACHINE_TPB), dyn2, s, a);
 				HIP_TRY(c, hipGetLastError());
 			}
 			HIP_TRY(c, hipEventRecord(c->ev[4], s));

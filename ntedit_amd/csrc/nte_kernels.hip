@@ -387,6 +387,10 @@ struct MachineArgs
 
 constexpr int MACHINE_TPB = 256;
 
+// WAVE = false: one thread per event (pass 1 / single pass).
+// WAVE = true : one wavefront per event (the sweep-only second pass): all 64 lanes run the
+//               same serial machine on one shared workspace and split the candidate sweep.
+template<bool WAVE>
 __global__ __launch_bounds__(MACHINE_TPB) void
 k_machine(MachineArgs a)
 {
@@ -396,8 +400,10 @@ k_machine(MachineArgs a)
 		s_tab[threadIdx.x] = a.tabs[threadIdx.x];
 	}
 	__syncthreads();
-	const u64 tid = (u64)blockIdx.x * MACHINE_TPB + threadIdx.x;
-	const u64 nthreads = (u64)gridDim.x * MACHINE_TPB;
+	const u64 gtid = (u64)blockIdx.x * MACHINE_TPB + threadIdx.x;
+	// "worker" = the unit that owns one event at a time: a thread or a wave
+	const u64 worker = WAVE ? (gtid >> 6) : gtid;
+	const u64 nworkers = WAVE ? ((u64)gridDim.x * MACHINE_TPB) >> 6 : (u64)gridDim.x * MACHINE_TPB;
 	const u64 W = a.p.node_window;
 
 	EventEnv env;
@@ -406,26 +412,33 @@ k_machine(MachineArgs a)
 	env.p = &a.p;
 	env.bloom = a.bloom;
 	env.rep = a.rep;
-	env.nodes = a.ws_nodes + tid * W;
-	env.ov_pos = a.ws_ov_pos + tid * W;
-	env.ov_chr = a.ws_ov_chr + tid * W;
+	env.nodes = a.ws_nodes + worker * W;
+	env.ov_pos = a.ws_ov_pos + worker * W;
+	env.ov_chr = a.ws_ov_chr + worker * W;
 	if (a.win_in_lds) {
-		// interleaved: byte i of thread t at s_win[i * 256 + t] (no bank conflicts when the
-		// lanes of a wave read the same i)
-		env.win = s_win + threadIdx.x;
-		env.win_stride = MACHINE_TPB;
+		if (WAVE) {
+			env.win = s_win + (threadIdx.x >> 6) * a.win_bytes;
+			env.win_stride = 1;
+		} else {
+			// interleaved: byte i of thread t at s_win[i * 256 + t] (no bank conflicts when
+			// the lanes of a wave read the same i)
+			env.win = s_win + threadIdx.x;
+			env.win_stride = MACHINE_TPB;
+		}
 	} else {
-		env.win = a.ws_win + tid * a.win_bytes;
+		env.win = a.ws_win + worker * a.win_bytes;
 		env.win_stride = 1;
 	}
-	env.prev = a.ws_prev + tid * W;
-	env.lps = a.ws_lps + tid * W;
+	env.prev = a.ws_prev + worker * W;
+	env.lps = a.ws_lps + worker * W;
 	env.arena = a.arena;
 	env.arena_next = a.arena_next;
 	env.arena_chunks = a.arena_chunks;
 	env.defer_sweeps = a.defer != 0;
+	env.wave_size = WAVE ? 64 : 1;
+	const bool leader = !WAVE || (threadIdx.x & 63) == 0;
 
-	for (u64 it = tid; it < a.n_events; it += nthreads) {
+	for (u64 it = worker; it < a.n_events; it += nworkers) {
 		const u64 ev = a.ev_list ? a.ev_list[it] : it;
 		const u64 g = a.events[ev];
 		// contig of g: last offset <= g
@@ -449,13 +462,17 @@ k_machine(MachineArgs a)
 			u32 cover_end = start;
 			m.run(start, cover_end);
 			fc = m.finish(start, cover_end);
-			if (m.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
-				atomicOr(a.status, m.flags & (EV_OVERFLOW | EV_ARENA_FULL));
-			} else if (m.flags & EV_DEFERRED) {
-				a.deferred[atomicAdd(a.n_deferred, 1u)] = (u32)ev;
+			if (leader) {
+				if (m.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
+					atomicOr(a.status, m.flags & (EV_OVERFLOW | EV_ARENA_FULL));
+				} else if (m.flags & EV_DEFERRED) {
+					a.deferred[atomicAdd(a.n_deferred, 1u)] = (u32)ev;
+				}
 			}
 		}
-		a.first_chunk[ev] = fc;
+		if (leader) {
+			a.first_chunk[ev] = fc;
+		}
 	}
 }
 

@@ -26,6 +26,18 @@
 
 namespace nte {
 
+// optional work counters for the host-side profile of the control logic (tests/hostsim)
+#if defined(NTE_COUNTERS)
+struct WorkCounters
+{
+	unsigned long long probes, fast_rolls, slow_rolls, ins_cands, del_cands, sweeps, windows_fast, windows_slow, windows_fail;
+};
+extern WorkCounters g_wc;
+#define NTE_COUNT(f, n) (g_wc.f += (n))
+#else
+#define NTE_COUNT(f, n) ((void)0)
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define NTE_ATOMIC_INC(p) atomicAdd((p), 1u)
 #else
@@ -56,6 +68,10 @@ struct EventEnv
 	u32 arena_chunks;
 	// pass 1 of the two-pass launch: stop (and emit nothing) at the first indel sweep
 	bool defer_sweeps;
+	// 1 = one thread per event; 64 = one wavefront per event: every lane runs the same
+	// serial machine on the same state (uniform control flow, same-value stores) and the
+	// lanes split the indel candidate sweep between them
+	u32 wave_size;
 };
 
 NTE_HD bool
@@ -117,6 +133,56 @@ struct Machine
 	{
 	}
 
+	// ------------------------------------------------------- wave helpers
+	NTE_HD u32
+	wave_lane() const
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		return e.wave_size > 1 ? (threadIdx.x & 63u) : 0u;
+#else
+		return 0;
+#endif
+	}
+
+	NTE_HD u64
+	wave_ballot(bool pred) const
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (e.wave_size > 1) {
+			return __ballot(pred);
+		}
+#endif
+		return pred ? 1ull : 0ull;
+	}
+
+	NTE_HD u32
+	wave_shfl(u32 v, u32 src) const
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (e.wave_size > 1) {
+			return (u32)__shfl((int)v, (int)src, 64);
+		}
+#endif
+		(void)src;
+		return v;
+	}
+
+	// one arena chunk for the whole wave (lane 0 allocates, everybody learns the index)
+	NTE_HD u32
+	alloc_chunk()
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (e.wave_size > 1) {
+			u32 c = 0;
+			if ((threadIdx.x & 63u) == 0) {
+				c = atomicAdd(e.arena_next, 1u);
+			}
+			return (u32)__shfl((int)c, 0, 64);
+		}
+#endif
+		return NTE_ATOMIC_INC(e.arena_next);
+	}
+
 	// ------------------------------------------------------------ output
 	NTE_HD void
 	emit(const Item& it)
@@ -125,7 +191,7 @@ struct Machine
 			return;
 		}
 		if (cur_chunk == NONE32 || fill == CHUNK_ITEMS) {
-			u32 c = NTE_ATOMIC_INC(e.arena_next);
+			u32 c = alloc_chunk();
 			if (c >= e.arena_chunks) {
 				flags |= EV_ARENA_FULL;
 				return;
@@ -368,6 +434,7 @@ struct Machine
 	NTE_HD bool
 	in_bloom(const HashState& s) const
 	{
+		NTE_COUNT(probes, 1);
 		return filter_contains(e.bloom, p, s);
 	}
 
@@ -387,6 +454,7 @@ struct Machine
 	NTE_HD void
 	roll_hash(HashState& s, u8 char_out, u8 char_in) const
 	{
+		NTE_COUNT(slow_rolls, 1);
 		hash_roll(s, e.tab, char_code(char_out), char_code(char_in));
 	}
 
@@ -775,6 +843,7 @@ struct Machine
 	NTE_HD u32
 	fast_deletion_support(u8 draft_code, u32 num_del) const
 	{
+		NTE_COUNT(del_cands, 1);
 		HashState ts = hs;
 		hash_changelast(ts, e.tab, draft_code, win_i(num_del - 1));
 		u32 cp = present_solid(ts) ? 1 : 0;
@@ -797,6 +866,7 @@ struct Machine
 	NTE_HD u32
 	fast_insertion_support(u8 draft_code, const u8* ins, u32 m) const
 	{
+		NTE_COUNT(ins_cands, 1);
 		HashState ts = hs;
 		hash_changelast(ts, e.tab, draft_code, char_code(ins[0]));
 		u32 cp = 0;
@@ -866,10 +936,81 @@ struct Machine
 		}
 	}
 
+	// Mode-0 sweep (first accepted candidate wins, ntedit.cpp:1587-1730), candidates
+	// evaluated wave_size at a time.  The reference tries, in this order,
+	//   ins[0], del(nd0), ins[1], del(nd0+1), ... , ins[D-1], del(nd0+D-1), ins[D], ins[D+1], ...
+	// (one deletion of growing length after each of the first D insertions, D = deletion
+	// lengths still untried at this failing position).  try number t of that list goes to
+	// lane t % wave_size; the first accepted try in list order is the result, so evaluating
+	// later tries speculatively cannot change it.  Needs the character window (win_ok).
+	NTE_HD bool
+	try_indels_first_accepted(u8 draft_char, u8 index_char, u32& num_deletions, Best& b)
+	{
+		const u32 W = e.wave_size;
+		const u32 lane = wave_lane();
+		const u8 draft_code = char_code(draft_char);
+		const u32 nd0 = num_deletions;
+		u32 D = nd0 <= p.max_deletions ? p.max_deletions - nd0 + 1 : 0;
+		if (D > p.ins_tries) {
+			D = p.ins_tries;
+		}
+		const u32 total = p.ins_tries + D;
+		for (u32 base = 0; base < total; base += W) {
+			const u32 t = base + lane;
+			u32 support = 0;
+			bool is_del = false;
+			u32 idx = 0; // insertion index or deletion length
+			if (t < total) {
+				if (t < 2 * D) {
+					is_del = (t & 1) != 0;
+					idx = is_del ? nd0 + (t >> 1) : (t >> 1);
+				} else {
+					idx = t - D;
+				}
+				if (is_del) {
+					support = fast_deletion_support(draft_code, idx);
+				} else {
+					u8 ins[12];
+					const u32 m = insertion_candidate(index_char, idx, ins);
+					const u32 cp = fast_insertion_support(draft_code, ins, m);
+					support = cp >= p.thr_edit ? cp : 0;
+				}
+			}
+			const u64 acc = wave_ballot(support > 0);
+			if (acc) {
+				u32 win = 0;
+				while (!((acc >> win) & 1)) {
+					win++;
+				}
+				const u32 tw = base + win;
+				const u32 sup = wave_shfl(support, win);
+				if (tw < 2 * D && (tw & 1)) {
+					b.edit_type = 3;
+					b.n_indel = nd0 + (tw >> 1);
+					for (u32 i = 0; i < b.n_indel && i < 12; i++) {
+						b.indel[i] = 0; // only the length of a deletion is consumed
+					}
+				} else {
+					const u32 ii = tw < 2 * D ? (tw >> 1) : tw - D;
+					b.edit_type = 2;
+					b.n_indel = insertion_candidate(index_char, ii, b.indel);
+				}
+				b.num_support = sup;
+				return true;
+			}
+		}
+		num_deletions = nd0 + D;
+		return false;
+	}
+
 	// ntedit.cpp:1548-1744
 	NTE_HD bool
 	try_indels(u8 draft_char, u8 index_char, u32& num_deletions, Best& b)
 	{
+		NTE_COUNT(sweeps, 1);
+		if (p.mode == 0 && win_ok) {
+			return try_indels_first_accepted(draft_char, index_char, num_deletions, b);
+		}
 		u32 temp_best_support = 0, temp_alt_support = 0;
 		u8 temp_best_indel[12];
 		u32 temp_best_n = 0;

@@ -8,7 +8,9 @@
 // against the oracle without a GPU.  It is never linked into the shipped
 // library and is not a fallback: ntedit_amd refuses to run without the HIP
 // extension.
+#define NTE_COUNTERS 1
 #include "../../ntedit_amd/csrc/nte_machine.h"
+namespace nte { WorkCounters g_wc; }
 #include "../../ntedit_amd/host/params.h"
 #include "../../ntedit_amd/host/render.h"
 
@@ -154,6 +156,7 @@ hostsim_polish(
 		env.arena_next = &arena_next;
 		env.arena_chunks = arena_chunks;
 		env.defer_sweeps = getenv("HOSTSIM_TWO_PASS") != nullptr;
+		env.wave_size = 1;
 		Machine m(env);
 		u32 start = (u32)(g - offsets[ci]);
 		u32 cover_end = start;
@@ -187,6 +190,10 @@ hostsim_polish(
 		if (fc != NONE32) {
 			ev_first.push_back(fc);
 		}
+	}
+	if (getenv("HOSTSIM_COUNTERS")) {
+		fprintf(stderr, "COUNTERS events %zu probes %llu slow_rolls %llu ins_cands %llu del_cands %llu sweeps %llu\n",
+		        events.size(), g_wc.probes, g_wc.slow_rolls, g_wc.ins_cands, g_wc.del_cands, g_wc.sweeps);
 	}
 	if (overflow) {
 		return NTEDIT_E_OVERFLOW;

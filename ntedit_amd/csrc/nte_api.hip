@@ -37,6 +37,13 @@ struct DevFilter
 
 } // namespace
 
+// page-locked host buffer (D2H at PCIe speed, no zero-fill); recycled through the context
+struct PinBuf
+{
+	void* p = nullptr;
+	size_t cap = 0;
+};
+
 struct ntedit_hip_ctx
 {
 	int device = 0;
@@ -54,12 +61,16 @@ struct ntedit_hip_ctx
 	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps, ws_win;
 	DevBuf offs, lens;
 	u32 cu_count = 256;
+	std::vector<PinBuf> pin_pool;
 };
 
 struct ntedit_hip_result
 {
-	std::vector<Item> arena;
-	std::vector<u32> ev_first;
+	ntedit_hip_ctx* owner = nullptr;
+	PinBuf arena_buf;      // arena copy (Items)
+	size_t arena_items = 0;
+	PinBuf first_buf;      // per-event first chunk, then compacted in place to ev_first
+	size_t n_ev_first = 0;
 	ntedit_hip_stats st;
 	nte_host::RenderStats rst;
 };
@@ -88,6 +99,12 @@ fail(ntedit_hip_ctx* c, int code, const char* fmt, ...)
 		}                                                                                        \
 	} while (0)
 
+// take a pinned buffer of at least `bytes` from the pool (or allocate one)
+int
+pin_take(ntedit_hip_ctx* c, size_t bytes, PinBuf* out);
+void
+pin_give(ntedit_hip_ctx* c, PinBuf& b);
+
 int
 ensure(ntedit_hip_ctx* c, DevBuf& b, size_t bytes)
 {
@@ -103,6 +120,48 @@ ensure(ntedit_hip_ctx* c, DevBuf& b, size_t bytes)
 	HIP_TRY(c, hipMalloc(&b.p, want));
 	b.cap = want;
 	return 0;
+}
+
+int
+pin_take(ntedit_hip_ctx* c, size_t bytes, PinBuf* out)
+{
+	int best = -1;
+	for (size_t i = 0; i < c->pin_pool.size(); i++) {
+		if (c->pin_pool[i].cap >= bytes && (best < 0 || c->pin_pool[i].cap < c->pin_pool[best].cap)) {
+			best = (int)i;
+		}
+	}
+	if (best >= 0) {
+		*out = c->pin_pool[best];
+		c->pin_pool.erase(c->pin_pool.begin() + best);
+		return 0;
+	}
+	// drop the smallest pooled buffer if the pool is getting large
+	if (c->pin_pool.size() >= 4) {
+		(void)hipHostFree(c->pin_pool.front().p);
+		c->pin_pool.erase(c->pin_pool.begin());
+	}
+	size_t want = bytes + bytes / 4 + 4096;
+	void* p = nullptr;
+	HIP_TRY(c, hipHostMalloc(&p, want, hipHostMallocDefault));
+	out->p = p;
+	out->cap = want;
+	return 0;
+}
+
+void
+pin_give(ntedit_hip_ctx* c, PinBuf& b)
+{
+	if (!b.p) {
+		return;
+	}
+	if (c) {
+		c->pin_pool.push_back(b);
+	} else {
+		(void)hipHostFree(b.p);
+	}
+	b.p = nullptr;
+	b.cap = 0;
 }
 
 void
@@ -312,6 +371,10 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 	for (DevBuf* b : bufs) {
 		release(*b);
 	}
+	for (auto& pb : c->pin_pool) {
+		(void)hipHostFree(pb.p);
+	}
+	c->pin_pool.clear();
 	if (c->d_tab) {
 		(void)hipFree(c->d_tab);
 	}
@@ -676,6 +739,7 @@ ntedit_hip_polish_batch(
 		}
 	}
 	ntedit_hip_result* r = new ntedit_hip_result();
+	r->owner = c;
 	memset(&r->st, 0, sizeof r->st);
 	r->st.bases = n;
 	*out = r;
@@ -683,6 +747,8 @@ ntedit_hip_polish_batch(
 		return 0;
 	}
 	auto bail = [&](int code) {
+		pin_give(c, r->arena_buf);
+		pin_give(c, r->first_buf);
 		delete r;
 		*out = nullptr;
 		return code;
@@ -846,19 +912,25 @@ ntedit_hip_polish_batch(
 			const u32 used = h_tail[0], status = h_tail[2];
 			if (status == 0) {
 				const u64 used_chunks = used < arena_chunks ? used : arena_chunks;
-				r->arena.resize((size_t)used_chunks * CHUNK_ITEMS);
-				std::vector<u32> first(n_events);
-				if (used_chunks) {
-					HIP_TRY(c, hipMemcpyAsync(r->arena.data(), c->arena.p, r->arena.size() * sizeof(Item), hipMemcpyDeviceToHost, s));
+				r->arena_items = (size_t)used_chunks * CHUNK_ITEMS;
+				if ((rc = pin_take(c, r->arena_items * sizeof(Item) + 16, &r->arena_buf)) ||
+				    (rc = pin_take(c, n_events * 4 + 16, &r->first_buf))) {
+					return bail(rc);
 				}
-				HIP_TRY(c, hipMemcpyAsync(first.data(), c->first_chunk.p, n_events * 4, hipMemcpyDeviceToHost, s));
+				if (used_chunks) {
+					HIP_TRY(c, hipMemcpyAsync(r->arena_buf.p, c->arena.p, r->arena_items * sizeof(Item), hipMemcpyDeviceToHost, s));
+				}
+				HIP_TRY(c, hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, n_events * 4, hipMemcpyDeviceToHost, s));
 				HIP_TRY(c, hipStreamSynchronize(s));
-				r->ev_first.reserve(used_chunks);
+				// keep the events that produced output, in position order (compacted in place)
+				u32* first = (u32*)r->first_buf.p;
+				size_t w = 0;
 				for (u64 i = 0; i < n_events; i++) {
 					if (first[i] != NONE32) {
-						r->ev_first.push_back(first[i]);
+						first[w++] = first[i];
 					}
 				}
+				r->n_ev_first = w;
 				break;
 			}
 			if (attempt >= 4) {
@@ -886,6 +958,12 @@ ntedit_hip_polish_batch(
 void
 ntedit_hip_result_free(ntedit_hip_result* r)
 {
+	if (!r) {
+		return;
+	}
+	// results must be freed before their context is destroyed
+	pin_give(r->owner, r->arena_buf);
+	pin_give(r->owner, r->first_buf);
 	delete r;
 }
 
@@ -938,10 +1016,10 @@ ntedit_hip_write_outputs(
 	ntedit_hip_result* rw = const_cast<ntedit_hip_result*>(r);
 	rw->rst = nte_host::RenderStats();
 	int rc = nte_host::render_batch(
-	    r->arena.data(),
-	    r->arena.size(),
-	    r->ev_first.data(),
-	    r->ev_first.size(),
+	    (const Item*)r->arena_buf.p,
+	    r->arena_items,
+	    (const u32*)r->first_buf.p,
+	    r->n_ev_first,
 	    bases,
 	    offsets,
 	    lens,

@@ -126,7 +126,7 @@ make_dev_params(
 	d.thr_edit_del = first_count(k, [&](uint32_t c) {
 		return (!ur && (float)c >= (fk / y)) || (ur && (float)c >= (1 + (fk / jump)) * Y);
 	});
-	uint32_t g = hp.start_grid ? hp.start_grid : 32;
+	uint32_t g = hp.start_grid ? hp.start_grid : 256;
 	if (g & (g - 1)) {
 		return NTEDIT_E_ARG;
 	}

@@ -90,6 +90,7 @@ class Polisher:
             raise NtEditHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
 
     def close(self):
+        # results hold page-locked buffers that belong to the context: free them first
         if self._h:
             self._lib.ntedit_hip_destroy(self._h)
             self._h = None

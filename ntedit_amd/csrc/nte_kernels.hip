@@ -391,7 +391,7 @@ constexpr int MACHINE_TPB = 256;
 // WAVE = true : one wavefront per event (the sweep-only second pass): all 64 lanes run the
 //               same serial machine on one shared workspace and split the candidate sweep.
 template<bool WAVE>
-__global__ __launch_bounds__(MACHINE_TPB) void
+__global__ __launch_bounds__(MACHINE_TPB, 4) void
 k_machine(MachineArgs a)
 {
 	__shared__ u64 s_tab[TAB_WORDS];

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--screen-only", action="store_true", help="time only the screening kernel (profiling aid)")
     ap.add_argument("--start-grid", type=int, default=0, help="event start grid override (tuning)")
+    ap.add_argument("--screen-mode", type=int, default=0, help="0 auto, 1 direct gather, 2 L2-partitioned")
     return ap.parse_args()
 
 
@@ -121,7 +122,7 @@ def main():
     dev = torch.device("cuda", local)
 
     pol = ntedit_amd.Polisher(local)
-    pol.set_params(ntedit_amd.default_params(start_grid=args.start_grid))
+    pol.set_params(ntedit_amd.default_params(start_grid=args.start_grid, screen_mode=args.screen_mode))
     t_setup = time.perf_counter()
     # same truth genome on every rank; rank 0 builds the filter and broadcasts it (RCCL)
     job = SyntheticJob(pol, args.bases, k=args.k, hash_num=args.hashes, filter_bytes=args.filter_bytes,

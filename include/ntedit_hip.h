@@ -60,6 +60,7 @@ typedef struct ntedit_hip_params
 	/* tuning, not part of the reference surface (0 = default) */
 	uint32_t start_grid;       /* extra event start every N positions in an absent run (power of 2) */
 	uint32_t node_window;      /* rope nodes kept live per event thread */
+	uint32_t screen_mode;      /* 0 auto, 1 direct gather kernel, 2 L2-partitioned (binned) pipeline */
 } ntedit_hip_params;
 
 /* defaults of ntedit.cpp:99-133 */

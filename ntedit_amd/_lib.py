@@ -33,6 +33,7 @@ class Params(ctypes.Structure):
         ("max_threshold", ctypes.c_uint32),
         ("start_grid", ctypes.c_uint32),
         ("node_window", ctypes.c_uint32),
+        ("screen_mode", ctypes.c_uint32),
     ]
 
 

@@ -60,6 +60,7 @@ struct ntedit_hip_ctx
 	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters, deferred;
 	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps, ws_win;
 	DevBuf offs, lens;
+	DevBuf bin_records, bin_totals, bin_bases, bin_work;
 	u32 cu_count = 256;
 	std::vector<PinBuf> pin_pool;
 };
@@ -228,6 +229,9 @@ refresh_params(ntedit_hip_ctx* c)
 	return 0;
 }
 
+bool binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_log2, u32* n_slices);
+int run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words, u32 slog, u32 n_slices);
+
 template<bool INSERT>
 int
 launch_screen(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words)
@@ -235,6 +239,12 @@ launch_screen(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d
 	const u64 blocks = (n + SCREEN_TILE - 1) / SCREEN_TILE;
 	if (blocks == 0) {
 		return 0;
+	}
+	if (!INSERT) {
+		u32 slog = 0, n_slices = 0;
+		if (binned_applicable(c, f, n, &slog, &n_slices)) {
+			return run_screen_binned(c, d_seq, n, f, d_bitmap, n_words, slog, n_slices);
+		}
 	}
 	if (blocks > 0x7FFFFFFFull) {
 		return fail(c, NTEDIT_E_ARG, "batch too large");
@@ -275,6 +285,128 @@ launch_screen(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d
 	}
 #undef NTE_LAUNCH
 	HIP_TRY(c, hipGetLastError());
+	return 0;
+}
+
+// ---- L2-partitioned ("binned") screening; see nte_kernels.hip
+bool
+binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_log2, u32* n_slices)
+{
+	const u32 mode = c->hp.screen_mode;
+	if (mode == 1 || f.hash_num == 0 || f.hash_num > 5) {
+		return false;
+	}
+	u32 slog = 24;
+	u64 ns = (f.bits + (1ULL << slog) - 1) >> slog;
+	while (ns > BIN_MAX_SLICES) {
+		slog++;
+		ns = (f.bits + (1ULL << slog) - 1) >> slog;
+	}
+	if (slog > 25) {
+		return false; // slices beyond 4 MiB would not stay in an XCD's L2
+	}
+	*slice_log2 = slog;
+	*n_slices = (u32)ns;
+	(void)n;
+	// Measured on MI355X (3 Gbp, 4 GiB filter, h=3, per 1 Gbp chunk): count 2.1 ms, write
+	// 38 ms (scattered 8-byte stores, ~80 G stores/s), L2-resident probe 18 ms (165 G
+	// probes/s) = 58 ms, the same as the direct kernel's 58.6 ms.  The partial-line store
+	// rate cancels the L2 win, so the pipeline is opt-in (screen_mode = 2) until the write
+	// stage is restructured; see DESIGN.md.
+	return mode == 2;
+}
+
+template<int MODE>
+void
+launch_bin(ntedit_hip_ctx* c, const BinArgs& a, u64 blocks)
+{
+	dim3 grid((unsigned)blocks), block(SCREEN_TPB);
+	size_t pad = 0;
+	if (MODE == BIN_WRITE) {
+		if (const char* e = getenv("NTEDIT_HIP_BIN_LDS_PAD")) {
+			pad = (size_t)strtoull(e, nullptr, 10);
+		}
+	}
+	const bool pow2 = a.f.mask != 0;
+#define NTE_BIN(H)                                                                               \
+	do {                                                                                         \
+		if (pow2) {                                                                              \
+			hipLaunchKernelGGL((k_bin<MODE, H, true>), grid, block, pad, c->stream, a);            \
+		} else {                                                                                 \
+			hipLaunchKernelGGL((k_bin<MODE, H, false>), grid, block, pad, c->stream, a);           \
+		}                                                                                        \
+	} while (0)
+	switch (a.f.hash_num) {
+	case 1:
+		NTE_BIN(1);
+		break;
+	case 2:
+		NTE_BIN(2);
+		break;
+	case 3:
+		NTE_BIN(3);
+		break;
+	case 4:
+		NTE_BIN(4);
+		break;
+	default:
+		NTE_BIN(5);
+		break;
+	}
+#undef NTE_BIN
+}
+
+int
+run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words, u32 slog, u32 n_slices)
+{
+	// records per chunk stay below 2^32 (LDS keeps 32-bit bases)
+	u64 chunk = ((1ULL << 32) - (1ULL << 22)) / f.hash_num;
+	if (chunk > (1ULL << 30)) {
+		chunk = 1ULL << 30;
+	}
+	if (const char* e = getenv("NTEDIT_HIP_BIN_CHUNK")) { // test hook: force several chunks
+		const u64 v = strtoull(e, nullptr, 10);
+		if (v >= (u64)SCREEN_TILE && v < chunk) {
+			chunk = v;
+		}
+	}
+	chunk = chunk / SCREEN_TILE * SCREEN_TILE;
+	const u64 first_chunk = n < chunk ? (n + SCREEN_TILE - 1) / SCREEN_TILE * SCREEN_TILE : chunk;
+	int rc;
+	if ((rc = ensure(c, c->bin_records, first_chunk * f.hash_num * 8)) ||
+	    (rc = ensure(c, c->bin_totals, (size_t)(n_slices + 1) * 8)) ||
+	    (rc = ensure(c, c->bin_bases, (size_t)(n_slices + 1) * 8)) ||
+	    (rc = ensure(c, c->bin_work, (size_t)(n_slices + 1) * 4))) {
+		return rc;
+	}
+	HIP_TRY(c, hipMemsetAsync(d_bitmap, 0, n_words * 8, c->stream));
+	for (u64 begin = 0; begin < n; begin += chunk) {
+		const u64 end = begin + chunk < n ? begin + chunk : n;
+		const u64 blocks = (end - begin + SCREEN_TILE - 1) / SCREEN_TILE;
+		BinArgs a;
+		a.seq = d_seq;
+		a.n = n;
+		a.chunk_begin = begin;
+		a.chunk_end = end;
+		a.f = f;
+		a.p = c->dp;
+		a.tabs = c->d_tab;
+		a.n_slices = n_slices;
+		a.slice_log2 = slog;
+		a.totals = (unsigned long long*)c->bin_totals.p;
+		a.records = (u64*)c->bin_records.p;
+		HIP_TRY(c, hipMemsetAsync(c->bin_totals.p, 0, (size_t)(n_slices + 1) * 8, c->stream));
+		HIP_TRY(c, hipMemsetAsync(c->bin_work.p, 0, (size_t)(n_slices + 1) * 4, c->stream));
+		launch_bin<BIN_COUNT>(c, a, blocks);
+		hipLaunchKernelGGL(
+		    k_bin_scan, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long*)c->bin_totals.p, n_slices,
+		    (unsigned long long*)c->bin_bases.p, (unsigned long long*)c->bin_totals.p);
+		launch_bin<BIN_WRITE>(c, a, blocks);
+		hipLaunchKernelGGL(
+		    k_bin_probe, dim3(c->cu_count * 8), dim3(PROBE_TPB), 0, c->stream, f.data, (const u64*)c->bin_records.p,
+		    (const unsigned long long*)c->bin_bases.p, n_slices, slog, (u32*)c->bin_work.p, (u32*)d_bitmap);
+		HIP_TRY(c, hipGetLastError());
+	}
 	return 0;
 }
 
@@ -367,7 +499,7 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 	}
 	DevBuf* bufs[] = { &c->seq,      &c->bitmap,   &c->block_counts, &c->block_offsets, &c->events,
 		               &c->first_chunk, &c->arena, &c->counters, &c->deferred,     &c->ws_nodes,      &c->ws_ov_pos,
-		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win,       &c->offs,          &c->lens };
+		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->bin_records, &c->bin_totals, &c->bin_bases, &c->bin_work,       &c->offs,          &c->lens };
 	for (DevBuf* b : bufs) {
 		release(*b);
 	}

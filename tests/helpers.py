@@ -31,11 +31,12 @@ class HipParams(ctypes.Structure):
         ("max_threshold", ctypes.c_uint32),
         ("start_grid", ctypes.c_uint32),
         ("node_window", ctypes.c_uint32),
+        ("screen_mode", ctypes.c_uint32),
     ]
 
 
 def default_params(**kw):
-    p = HipParams(100, 5, 5, 9.0, 5.0, 0.5, 0.5, 0, 3, 0, 0, 0, 1, 255, 0, 0)
+    p = HipParams(100, 5, 5, 9.0, 5.0, 0.5, 0.5, 0, 3, 0, 0, 0, 1, 255, 0, 0, 0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p

@@ -133,3 +133,44 @@ def test_demo_ecoli(tmp_path, oracle_build):
     assert len(ref_rows & got_rows) >= 0.99 * len(ref_rows)
     assert open(ref_tsv).readline() == open(str(tmp_path / "g_changes.tsv")).readline()
     assert st.bases > 4_600_000
+
+
+@pytest.mark.parametrize("ci", [0, 1, 3, 16, 23, 24, 25])
+def test_binned_screen_matches_oracle(tmp_path, ci, oracle_build, monkeypatch):
+    """the L2-partitioned screening pipeline (count / scan / write / probe) gives the same bitmap
+    as the oracle, incl. several chunks, non-power-of-two filters and 1..6 hashes"""
+    import ntedit_amd
+    monkeypatch.setenv("NTEDIT_HIP_BIN_CHUNK", str(3 * 16384))
+    case_kw, _ = H.PARITY_CONFIGS[ci]
+    case = H.make_case(str(tmp_path), 4000 + ci, **case_kw)
+    bf = H.load_bf(case["bf"])
+    blob, offs, lens, names = H.pack_batch(H.read_fasta(case["draft"]))
+    want = H.oracle_screen(blob, bf)
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.set_filter(bf["data"], bf["hash_num"], bf["k"])
+        pol.set_params(ntedit_amd.default_params(screen_mode=2))
+        got = pol.screen(blob)
+        pol.set_params(ntedit_amd.default_params(screen_mode=1))
+        direct = pol.screen(blob)
+    finally:
+        pol.close()
+    assert np.array_equal(direct, want)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("ci", [0, 8, 10, 23])
+def test_polish_with_binned_screen(tmp_path, ci, oracle_build):
+    case_kw, par_kw = H.PARITY_CONFIGS[ci]
+    case = H.make_case(str(tmp_path), 5000 + ci, **case_kw)
+    hp = H.default_params(**par_kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), case["rep"])
+    pol = _fresh()
+    try:
+        _load_filters(pol, case)
+        pol.set_params(_hip_params(screen_mode=2, **par_kw))
+        pol.polish_records(H.read_fasta(case["draft"]), str(tmp_path / "g"))
+    finally:
+        pol.close()
+    assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "g_changes.tsv"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "g_edited.fa"), shallow=False)

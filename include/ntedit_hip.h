@@ -152,10 +152,12 @@ typedef struct ntedit_hip_stats
 	uint64_t events_deferred; /* events re-run by the sweep-only second launch */
 	uint64_t events_applied; /* events that survive the serial-order filter  */
 	uint64_t substitutions, insertions, deletions; /* rope/record counts     */
-	float ms_screen;         /* HIP-event time of the screening kernel       */
-	float ms_extract;        /* event extraction kernels                     */
-	float ms_machine;        /* event machine kernel                         */
-	float ms_total;          /* first kernel start -> last kernel end        */
+	float ms_screen;         /* HIP-event time of the screening launches (sum) */
+	float ms_extract;        /* (folded into ms_machine's stream; 0)          */
+	float ms_machine;        /* event machine launches (sum); overlaps screening when pipelined */
+	float ms_total;          /* first kernel start -> edit records in host memory */
+	uint32_t screen_launches; /* k_screen launches of this batch (pipeline chunks) */
+	uint32_t reserved;
 } ntedit_hip_stats;
 int ntedit_hip_result_stats(const ntedit_hip_result* r, ntedit_hip_stats* s);
 

@@ -51,6 +51,8 @@ class Stats(ctypes.Structure):
         ("ms_extract", ctypes.c_float),
         ("ms_machine", ctypes.c_float),
         ("ms_total", ctypes.c_float),
+        ("screen_launches", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
     ]
 
 

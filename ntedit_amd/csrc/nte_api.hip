@@ -48,6 +48,8 @@ struct ntedit_hip_ctx
 {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t stream2 = nullptr; // event extraction + machine of the chunk pipeline
+	std::vector<hipEvent_t> chunk_ev; // 2 per chunk on `stream` (screen begin / end)
 	DevFilter filt[2];
 	ntedit_hip_params hp;
 	DevParams dp;
@@ -230,37 +232,46 @@ refresh_params(ntedit_hip_ctx* c)
 }
 
 bool binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_log2, u32* n_slices);
-int run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words, u32 slog, u32 n_slices);
+int run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words, u32 slog, u32 n_slices, hipStream_t stream = nullptr, u64 pos_begin = 0, u64 pos_end = ~0ULL);
 
+// Launches k_screen over tiles [first_tile, first_tile + n_tiles) of the batch on `stream`.
+// lds_pad > 0 lowers the kernel's occupancy (its speed does not depend on it: it is bound by
+// the L2-miss path from 2 workgroups per CU upwards) so that k_machine can share the CUs.
 template<bool INSERT>
 int
-launch_screen(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words)
+launch_screen_tiles(
+    ntedit_hip_ctx* c,
+    hipStream_t stream,
+    const u8* d_seq,
+    u64 n,
+    const Filter& f,
+    u64* d_bitmap,
+    u64 n_words,
+    u64 first_tile,
+    u64 n_tiles,
+    size_t lds_pad)
 {
-	const u64 blocks = (n + SCREEN_TILE - 1) / SCREEN_TILE;
-	if (blocks == 0) {
+	if (n_tiles == 0) {
 		return 0;
 	}
-	if (!INSERT) {
-		u32 slog = 0, n_slices = 0;
-		if (binned_applicable(c, f, n, &slog, &n_slices)) {
-			return run_screen_binned(c, d_seq, n, f, d_bitmap, n_words, slog, n_slices);
-		}
-	}
-	if (blocks > 0x7FFFFFFFull) {
+	if (n_tiles > 0x7FFFFFFFull) {
 		return fail(c, NTEDIT_E_ARG, "batch too large");
 	}
-	dim3 grid((unsigned)blocks), block(SCREEN_TPB);
+	dim3 grid((unsigned)n_tiles), block(SCREEN_TPB);
 	const bool pow2 = f.mask != 0;
+	if (const char* e = getenv("NTEDIT_HIP_SCREEN_LDS_PAD")) { // tuning hook
+		lds_pad = (size_t)strtoull(e, nullptr, 10);
+	}
 #define NTE_LAUNCH(H)                                                                            \
 	do {                                                                                         \
 		if (pow2) {                                                                              \
 			hipLaunchKernelGGL(                                                                  \
-			    (k_screen<H, true, INSERT>), grid, block, 0, c->stream, d_seq, n, f, c->dp,      \
-			    c->d_tab, d_bitmap, n_words);                                                    \
+			    (k_screen<H, true, INSERT>), grid, block, lds_pad, stream, d_seq, n, f, c->dp,   \
+			    c->d_tab, d_bitmap, n_words, first_tile);                                        \
 		} else {                                                                                 \
 			hipLaunchKernelGGL(                                                                  \
-			    (k_screen<H, false, INSERT>), grid, block, 0, c->stream, d_seq, n, f, c->dp,     \
-			    c->d_tab, d_bitmap, n_words);                                                    \
+			    (k_screen<H, false, INSERT>), grid, block, lds_pad, stream, d_seq, n, f, c->dp,  \
+			    c->d_tab, d_bitmap, n_words, first_tile);                                        \
 		}                                                                                        \
 	} while (0)
 	switch (f.hash_num) {
@@ -286,6 +297,49 @@ launch_screen(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d
 #undef NTE_LAUNCH
 	HIP_TRY(c, hipGetLastError());
 	return 0;
+}
+
+template<bool INSERT>
+int
+launch_screen(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words)
+{
+	const u64 blocks = (n + SCREEN_TILE - 1) / SCREEN_TILE;
+	if (blocks == 0) {
+		return 0;
+	}
+	if (!INSERT) {
+		u32 slog = 0, n_slices = 0;
+		if (binned_applicable(c, f, n, &slog, &n_slices)) {
+			double frac = 1.0; // share of the batch that goes through the binned pipeline
+			if (const char* e = getenv("NTEDIT_HIP_HYBRID_FRAC")) {
+				frac = atof(e);
+			}
+			if (frac >= 1.0) {
+				return run_screen_binned(c, d_seq, n, f, d_bitmap, n_words, slog, n_slices);
+			}
+			// hybrid: the direct kernel (bound by the L2-miss path) and the binned pipeline
+			// (bound by record stores + L2 hits) run side by side on two streams
+			u64 split_tile = (u64)((double)blocks * (1.0 - frac));
+			if (split_tile > blocks) {
+				split_tile = blocks;
+			}
+			const u64 split_pos = split_tile * SCREEN_TILE;
+			HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+			HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
+			int rc = launch_screen_tiles<false>(c, c->stream, d_seq, n, f, d_bitmap, n_words, 0, split_tile, 44 * 1024);
+			if (rc) {
+				return rc;
+			}
+			rc = run_screen_binned(c, d_seq, n, f, d_bitmap, n_words, slog, n_slices, c->stream2, split_pos, n);
+			if (rc) {
+				return rc;
+			}
+			HIP_TRY(c, hipEventRecord(c->ev[5], c->stream2));
+			HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[5], 0));
+			return 0;
+		}
+	}
+	return launch_screen_tiles<INSERT>(c, c->stream, d_seq, n, f, d_bitmap, n_words, 0, blocks, 0);
 }
 
 // ---- L2-partitioned ("binned") screening; see nte_kernels.hip
@@ -318,8 +372,9 @@ binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_lo
 
 template<int MODE>
 void
-launch_bin(ntedit_hip_ctx* c, const BinArgs& a, u64 blocks)
+launch_bin(ntedit_hip_ctx* c, hipStream_t stream, const BinArgs& a, u64 blocks)
 {
+	(void)c;
 	dim3 grid((unsigned)blocks), block(SCREEN_TPB);
 	size_t pad = 0;
 	if (MODE == BIN_WRITE) {
@@ -331,9 +386,9 @@ launch_bin(ntedit_hip_ctx* c, const BinArgs& a, u64 blocks)
 #define NTE_BIN(H)                                                                               \
 	do {                                                                                         \
 		if (pow2) {                                                                              \
-			hipLaunchKernelGGL((k_bin<MODE, H, true>), grid, block, pad, c->stream, a);            \
+			hipLaunchKernelGGL((k_bin<MODE, H, true>), grid, block, pad, stream, a);               \
 		} else {                                                                                 \
-			hipLaunchKernelGGL((k_bin<MODE, H, false>), grid, block, pad, c->stream, a);           \
+			hipLaunchKernelGGL((k_bin<MODE, H, false>), grid, block, pad, stream, a);              \
 		}                                                                                        \
 	} while (0)
 	switch (a.f.hash_num) {
@@ -357,8 +412,14 @@ launch_bin(ntedit_hip_ctx* c, const BinArgs& a, u64 blocks)
 }
 
 int
-run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words, u32 slog, u32 n_slices)
+run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words, u32 slog, u32 n_slices, hipStream_t stream, u64 pos_begin, u64 pos_end)
 {
+	if (!stream) {
+		stream = c->stream;
+	}
+	if (pos_end > n) {
+		pos_end = n;
+	}
 	// records per chunk stay below 2^32 (LDS keeps 32-bit bases)
 	u64 chunk = ((1ULL << 32) - (1ULL << 22)) / f.hash_num;
 	if (chunk > (1ULL << 30)) {
@@ -371,7 +432,8 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		}
 	}
 	chunk = chunk / SCREEN_TILE * SCREEN_TILE;
-	const u64 first_chunk = n < chunk ? (n + SCREEN_TILE - 1) / SCREEN_TILE * SCREEN_TILE : chunk;
+	const u64 span = pos_end - pos_begin;
+	const u64 first_chunk = span < chunk ? (span + SCREEN_TILE - 1) / SCREEN_TILE * SCREEN_TILE : chunk;
 	int rc;
 	if ((rc = ensure(c, c->bin_records, first_chunk * f.hash_num * 8)) ||
 	    (rc = ensure(c, c->bin_totals, (size_t)(n_slices + 1) * 8)) ||
@@ -379,9 +441,13 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 	    (rc = ensure(c, c->bin_work, (size_t)(n_slices + 1) * 4))) {
 		return rc;
 	}
-	HIP_TRY(c, hipMemsetAsync(d_bitmap, 0, n_words * 8, c->stream));
-	for (u64 begin = 0; begin < n; begin += chunk) {
-		const u64 end = begin + chunk < n ? begin + chunk : n;
+	{
+		// the probe stage ORs into the bitmap: clear the words of the range first
+		const u64 w0 = pos_begin / 64, w1 = (pos_end + 63) / 64 < n_words ? (pos_end + 63) / 64 : n_words;
+		HIP_TRY(c, hipMemsetAsync(d_bitmap + w0, 0, (w1 - w0) * 8, stream));
+	}
+	for (u64 begin = pos_begin; begin < pos_end; begin += chunk) {
+		const u64 end = begin + chunk < pos_end ? begin + chunk : pos_end;
 		const u64 blocks = (end - begin + SCREEN_TILE - 1) / SCREEN_TILE;
 		BinArgs a;
 		a.seq = d_seq;
@@ -395,15 +461,15 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		a.slice_log2 = slog;
 		a.totals = (unsigned long long*)c->bin_totals.p;
 		a.records = (u64*)c->bin_records.p;
-		HIP_TRY(c, hipMemsetAsync(c->bin_totals.p, 0, (size_t)(n_slices + 1) * 8, c->stream));
-		HIP_TRY(c, hipMemsetAsync(c->bin_work.p, 0, (size_t)(n_slices + 1) * 4, c->stream));
-		launch_bin<BIN_COUNT>(c, a, blocks);
+		HIP_TRY(c, hipMemsetAsync(c->bin_totals.p, 0, (size_t)(n_slices + 1) * 8, stream));
+		HIP_TRY(c, hipMemsetAsync(c->bin_work.p, 0, (size_t)(n_slices + 1) * 4, stream));
+		launch_bin<BIN_COUNT>(c, stream, a, blocks);
 		hipLaunchKernelGGL(
-		    k_bin_scan, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long*)c->bin_totals.p, n_slices,
+		    k_bin_scan, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)c->bin_totals.p, n_slices,
 		    (unsigned long long*)c->bin_bases.p, (unsigned long long*)c->bin_totals.p);
-		launch_bin<BIN_WRITE>(c, a, blocks);
+		launch_bin<BIN_WRITE>(c, stream, a, blocks);
 		hipLaunchKernelGGL(
-		    k_bin_probe, dim3(c->cu_count * 8), dim3(PROBE_TPB), 0, c->stream, f.data, (const u64*)c->bin_records.p,
+		    k_bin_probe, dim3(c->cu_count * 8), dim3(PROBE_TPB), 0, stream, f.data, (const u64*)c->bin_records.p,
 		    (const unsigned long long*)c->bin_bases.p, n_slices, slog, (u32*)c->bin_work.p, (u32*)d_bitmap);
 		HIP_TRY(c, hipGetLastError());
 	}
@@ -470,7 +536,7 @@ ntedit_hip_create(int device, ntedit_hip_ctx** out)
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
 		c->cu_count = (u32)prop.multiProcessorCount;
 	}
-	if (hipStreamCreate(&c->stream) != hipSuccess) {
+	if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess) {
 		delete c;
 		return NTEDIT_E_DEVICE;
 	}
@@ -514,6 +580,13 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 		if (e) {
 			(void)hipEventDestroy(e);
 		}
+	}
+	for (auto& e : c->chunk_ev) {
+		(void)hipEventDestroy(e);
+	}
+	if (c->stream2) {
+		(void)hipStreamSynchronize(c->stream2);
+		(void)hipStreamDestroy(c->stream2);
 	}
 	if (c->stream) {
 		(void)hipStreamDestroy(c->stream);
@@ -891,29 +964,73 @@ ntedit_hip_polish_batch(
 	if ((rc = stage_bases(c, bases, n, on_device, &d_seq))) {
 		return bail(rc);
 	}
-	if ((rc = ensure(c, c->bitmap, (n_words + 1) * 8)) || (rc = ensure(c, c->counters, 64)) ||
+	if ((rc = ensure(c, c->bitmap, (n_words + 1) * 8)) || (rc = ensure(c, c->counters, 256)) ||
 	    (rc = ensure(c, c->offs, (size_t)n_contigs * 8)) || (rc = ensure(c, c->lens, (size_t)n_contigs * 4))) {
 		return bail(rc);
 	}
-	const u64 n_sblocks = (n_words + ST_TPB - 1) / ST_TPB;
-	if ((rc = ensure(c, c->block_counts, n_sblocks * 4)) || (rc = ensure(c, c->block_offsets, n_sblocks * 8))) {
-		return bail(rc);
-	}
 	u64* d_bitmap = (u64*)c->bitmap.p;
-	unsigned long long* d_counters = (unsigned long long*)c->counters.p;
-	hipStream_t s = c->stream;
-	HIP_TRY(c, hipMemcpyAsync(c->offs.p, offsets, (size_t)n_contigs * 8, hipMemcpyHostToDevice, s));
-	HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n_contigs * 4, hipMemcpyHostToDevice, s));
-	HIP_TRY(c, hipMemsetAsync(d_counters, 0, 64, s));
+	hipStream_t sA = c->stream;  // screening
+	hipStream_t sB = c->stream2; // event extraction + event machine
+	HIP_TRY(c, hipMemcpyAsync(c->offs.p, offsets, (size_t)n_contigs * 8, hipMemcpyHostToDevice, sA));
+	HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n_contigs * 4, hipMemcpyHostToDevice, sA));
 
-	// ---- step 1: screen
-	HIP_TRY(c, hipEventRecord(c->ev[0], s));
-	if ((rc = launch_screen<false>(c, d_seq, n, dev_filter(c->filt[0]), d_bitmap, n_words))) {
-		return bail(rc);
+	// ---- chunk plan: whole contigs, cut at SCREEN_TILE boundaries of the screening pass.
+	// Chunk j's screening covers tiles [t0, t1) with t1 = ceil(end of its last contig / TILE),
+	// so everything its events can touch has been screened when its screening launch ends.
+	struct Chunk
+	{
+		u32 c0, c1;   // contigs [c0, c1)
+		u64 b0, b1;   // byte range of those contigs (incl. their separators)
+		u64 t0, t1;   // screening tiles
+	};
+	std::vector<Chunk> chunks;
+	{
+		const u64 total_tiles = (n + SCREEN_TILE - 1) / SCREEN_TILE;
+		// Measured (3 Gbp, MI355X): overlapping the event machine of chunk j with the screening
+		// of chunk j+1 does not pay -- both are bound by the L2-miss path, the machine kernels
+		// just get slower (2 chunks 339 ms, 8 chunks 370 ms vs 331 ms for one) -- so the
+		// default is a single chunk; the chunk pipeline stays available (and tested) for
+		// bounded-memory operation.
+		u64 target = n + 1;
+		if (const char* e = getenv("NTEDIT_HIP_CHUNK_BYTES")) { // test hook: force many chunks
+			const u64 v = strtoull(e, nullptr, 10);
+			if (v > 0) {
+				target = v;
+			}
+		}
+		u32 c0 = 0;
+		u64 t_prev = 0;
+		while (c0 < n_contigs) {
+			u32 c1 = c0;
+			const u64 b0 = offsets[c0];
+			u64 b1 = b0;
+			while (c1 < n_contigs && (c1 == c0 || offsets[c1] + lens[c1] + 1 - b0 <= target)) {
+				b1 = c1 + 1 < n_contigs ? offsets[c1 + 1] : n;
+				c1++;
+			}
+			Chunk ch;
+			ch.c0 = c0;
+			ch.c1 = c1;
+			ch.b0 = c0 == 0 ? 0 : b0;
+			ch.b1 = b1;
+			ch.t0 = t_prev;
+			ch.t1 = c1 == n_contigs ? total_tiles : (b1 + SCREEN_TILE - 1) / SCREEN_TILE;
+			if (ch.t1 < ch.t0) {
+				ch.t1 = ch.t0;
+			}
+			t_prev = ch.t1;
+			chunks.push_back(ch);
+			c0 = c1;
+		}
 	}
-	HIP_TRY(c, hipEventRecord(c->ev[1], s));
+	const size_t n_ch = chunks.size();
+	const bool pipelined = n_ch > 1;
+	while (c->chunk_ev.size() < 2 * n_ch) {
+		hipEvent_t e;
+		HIP_TRY(c, hipEventCreate(&e));
+		c->chunk_ev.push_back(e);
+	}
 
-	// ---- event starts
 	const u32 grid = c->dp.start_grid;
 	u64 grid_lo = 0;
 	if (grid < 64) {
@@ -921,69 +1038,140 @@ ntedit_hip_polish_batch(
 			grid_lo |= 1ULL << b;
 		}
 	}
-	hipLaunchKernelGGL(
-	    k_count_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, s, d_bitmap, n_words, grid_lo, grid,
-	    (u32*)c->block_counts.p, d_counters);
-	hipLaunchKernelGGL(
-	    k_scan_counts, dim3(1), dim3(1024), 0, s, (const u32*)c->block_counts.p, n_sblocks,
-	    (unsigned long long*)c->block_offsets.p, d_counters);
-	unsigned long long h_counters[2] = { 0, 0 };
-	HIP_TRY(c, hipMemcpyAsync(h_counters, d_counters, 16, hipMemcpyDeviceToHost, s));
-	HIP_TRY(c, hipStreamSynchronize(s));
-	const u64 n_events = h_counters[1];
-	r->st.absent_kmers = h_counters[0];
-	r->st.events = n_events;
-	if (n_events > 0) {
-		if ((rc = ensure(c, c->events, n_events * 8)) || (rc = ensure(c, c->first_chunk, n_events * 4))) {
+	const Filter f0 = dev_filter(c->filt[0]);
+	// with more than one chunk the screening kernel is held to 2 workgroups per CU (its speed
+	// is set by the L2-miss path, not by occupancy) so the machine kernels of the previous
+	// chunk get wave slots, registers and LDS on every CU
+	const size_t screen_pad = pipelined ? 44 * 1024 : 0;
+
+	u64 arena_chunks = n / 160 + 65536;
+	if (arena_chunks * CHUNK_ITEMS * sizeof(Item) < c->arena.cap) {
+		arena_chunks = c->arena.cap / (CHUNK_ITEMS * sizeof(Item));
+	}
+	for (int attempt = 0;; attempt++) {
+		if (arena_chunks > 0xFFFFFFF0ull) {
+			return bail(fail(c, NTEDIT_E_OVERFLOW, "edit-record arena exceeds 2^32 chunks"));
+		}
+		if ((rc = ensure(c, c->arena, arena_chunks * CHUNK_ITEMS * sizeof(Item)))) {
 			return bail(rc);
 		}
-		hipLaunchKernelGGL(
-		    k_write_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, s, d_bitmap, n_words, grid_lo, grid,
-		    (const unsigned long long*)c->block_offsets.p, (u64*)c->events.p);
-	}
-	HIP_TRY(c, hipEventRecord(c->ev[2], s));
-	HIP_TRY(c, hipEventRecord(c->ev[3], s));
+		// counters layout (bytes): [0] absent k-mers u64, [8] starts of the current chunk u64,
+		// [32] arena cursor u32, [40] status u32, [44] deferred count u32
+		HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 256, sA));
+		HIP_TRY(c, hipStreamSynchronize(sA));
+		unsigned long long* d_counters = (unsigned long long*)c->counters.p;
+		u32* d_arena_next = (u32*)((char*)c->counters.p + 32);
+		u32* d_status = (u32*)((char*)c->counters.p + 40);
+		u32* d_ndef = (u32*)((char*)c->counters.p + 44);
 
-	// ---- steps 2-5: event machine (retry with more room if it overflows)
-	if (n_events > 0) {
-		u64 arena_chunks = n_events + n_events / 2 + 4096;
-		for (int attempt = 0;; attempt++) {
+		// ---- stream A: every chunk's screening, back to back
+		HIP_TRY(c, hipEventRecord(c->ev[0], sA));
+		if (!pipelined) {
+			HIP_TRY(c, hipEventRecord(c->chunk_ev[0], sA));
+			if ((rc = launch_screen<false>(c, d_seq, n, f0, d_bitmap, n_words))) {
+				return bail(rc);
+			}
+			HIP_TRY(c, hipEventRecord(c->chunk_ev[1], sA));
+		} else {
+			for (size_t j = 0; j < n_ch; j++) {
+				HIP_TRY(c, hipEventRecord(c->chunk_ev[2 * j], sA));
+				if ((rc = launch_screen_tiles<false>(
+				         c, sA, d_seq, n, f0, d_bitmap, n_words, chunks[j].t0, chunks[j].t1 - chunks[j].t0, screen_pad))) {
+					return bail(rc);
+				}
+				HIP_TRY(c, hipEventRecord(c->chunk_ev[2 * j + 1], sA));
+			}
+		}
+		HIP_TRY(c, hipEventRecord(c->ev[1], sA));
+
+		// ---- stream B: per chunk, as soon as its screening is done
+		u64 ev_total = 0;      // events of the chunks processed so far
+		u64 absent_total = 0, deferred_total = 0;
+		u32 status = 0;
+		float ms_extract = 0.f, ms_machine = 0.f;
+		bool first_b = true;
+		for (size_t j = 0; j < n_ch && status == 0; j++) {
+			const Chunk& ch = chunks[j];
+			HIP_TRY(c, hipStreamWaitEvent(sB, c->chunk_ev[2 * j + 1], 0));
+			if (first_b) {
+				HIP_TRY(c, hipEventRecord(c->ev[2], sB));
+				first_b = false;
+			}
+			const u64 w0 = ch.b0 / 64, w1 = (ch.b1 + 63) / 64;
+			const u64 n_sblocks = (w1 - w0 + ST_TPB - 1) / ST_TPB;
+			if (n_sblocks == 0) {
+				continue;
+			}
+			if ((rc = ensure(c, c->block_counts, n_sblocks * 4)) || (rc = ensure(c, c->block_offsets, n_sblocks * 8))) {
+				return bail(rc);
+			}
+			HIP_TRY(c, hipMemsetAsync((char*)c->counters.p + 8, 0, 8, sB));
+			hipLaunchKernelGGL(
+			    k_count_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_bitmap, w0, w1, ch.b0, ch.b1, grid_lo,
+			    grid, (u32*)c->block_counts.p, d_counters);
+			hipLaunchKernelGGL(
+			    k_scan_counts, dim3(1), dim3(1024), 0, sB, (const u32*)c->block_counts.p, n_sblocks,
+			    (unsigned long long*)c->block_offsets.p, d_counters);
+			unsigned long long h_counters[2] = { 0, 0 };
+			HIP_TRY(c, hipMemcpyAsync(h_counters, d_counters, 16, hipMemcpyDeviceToHost, sB));
+			HIP_TRY(c, hipStreamSynchronize(sB));
+			const u64 n_ev = h_counters[1];
+			absent_total = h_counters[0];
+			if (n_ev == 0) {
+				continue;
+			}
+			if (ev_total + n_ev > 0xFFFFFFF0ull) {
+				return bail(fail(c, NTEDIT_E_OVERFLOW, "more than 2^32 events in one batch"));
+			}
+			// grow-only buffers; (re)allocation happens on the first batches only
+			if (ev_total + n_ev > c->events.cap / 8 || ev_total + n_ev > c->first_chunk.cap / 4) {
+				// keep what earlier chunks wrote: allocate bigger buffers and copy
+				const u64 want = (ev_total + n_ev) * 2 + 1024;
+				DevBuf ne, nf;
+				if ((rc = ensure(c, ne, want * 8)) || (rc = ensure(c, nf, want * 4))) {
+					return bail(rc);
+				}
+				if (ev_total) {
+					HIP_TRY(c, hipMemcpyAsync(ne.p, c->events.p, ev_total * 8, hipMemcpyDeviceToDevice, sB));
+					HIP_TRY(c, hipMemcpyAsync(nf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToDevice, sB));
+					HIP_TRY(c, hipStreamSynchronize(sB));
+				}
+				release(c->events);
+				release(c->first_chunk);
+				c->events = ne;
+				c->first_chunk = nf;
+			}
+			if ((rc = ensure(c, c->deferred, n_ev * 4))) {
+				return bail(rc);
+			}
+			u64* d_events = (u64*)c->events.p + ev_total;
+			u32* d_first = (u32*)c->first_chunk.p + ev_total;
+			hipLaunchKernelGGL(
+			    k_write_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_bitmap, w0, w1, ch.b0, ch.b1, grid_lo,
+			    grid, (const unsigned long long*)c->block_offsets.p, d_events);
+
 			const u64 max_threads = (u64)c->cu_count * 2048;
-			u64 threads = n_events < max_threads ? n_events : max_threads;
+			u64 threads = n_ev < max_threads ? n_ev : max_threads;
 			const u64 blocks = (threads + MACHINE_TPB - 1) / MACHINE_TPB;
 			threads = blocks * MACHINE_TPB;
 			const u64 W = c->dp.node_window;
-			if (arena_chunks > 0xFFFFFFF0ull) {
-				return bail(fail(c, NTEDIT_E_OVERFLOW, "edit-record arena exceeds 2^32 chunks"));
-			}
-			if ((rc = ensure(c, c->arena, arena_chunks * CHUNK_ITEMS * sizeof(Item))) ||
-			    (rc = ensure(c, c->ws_nodes, threads * W * sizeof(Node))) ||
+			if ((rc = ensure(c, c->ws_nodes, threads * W * sizeof(Node))) ||
 			    (rc = ensure(c, c->ws_ov_pos, threads * W * 4)) || (rc = ensure(c, c->ws_ov_chr, threads * W)) ||
 			    (rc = ensure(c, c->ws_prev, threads * W)) || (rc = ensure(c, c->ws_lps, threads * W * 2))) {
 				return bail(rc);
 			}
-			if (n_events > 0xFFFFFFF0ull) {
-				return bail(fail(c, NTEDIT_E_OVERFLOW, "more than 2^32 events in one batch"));
-			}
-			if ((rc = ensure(c, c->deferred, n_events * 4))) {
-				return bail(rc);
-			}
-			u32* d_arena_next = (u32*)((char*)c->counters.p + 32);
-			u32* d_status = (u32*)((char*)c->counters.p + 40);
-			u32* d_ndef = (u32*)((char*)c->counters.p + 44);
-			HIP_TRY(c, hipMemsetAsync((char*)c->counters.p + 32, 0, 16, s));
 			MachineArgs a;
 			a.seq = d_seq;
 			a.offsets = (const u64*)c->offs.p;
 			a.lens = (const u32*)c->lens.p;
 			a.n_contigs = n_contigs;
 			a.bitmap = d_bitmap;
-			a.events = (const u64*)c->events.p;
-			a.n_events = n_events;
+			a.events = d_events;
+			a.n_events = n_ev;
 			a.tabs = c->d_tab;
 			a.p = c->dp;
-			a.bloom = dev_filter(c->filt[0]);
-			a.rep = c->filt[1].set ? dev_filter(c->filt[1]) : dev_filter(c->filt[0]);
+			a.bloom = f0;
+			a.rep = c->filt[1].set ? dev_filter(c->filt[1]) : f0;
 			a.ws_nodes = (Node*)c->ws_nodes.p;
 			a.ws_ov_pos = (u32*)c->ws_ov_pos.p;
 			a.ws_ov_chr = (u8*)c->ws_ov_chr.p;
@@ -1002,88 +1190,111 @@ ntedit_hip_polish_batch(
 			a.arena = (Item*)c->arena.p;
 			a.arena_next = d_arena_next;
 			a.arena_chunks = (u32)arena_chunks;
-			a.first_chunk = (u32*)c->first_chunk.p;
+			a.first_chunk = d_first;
 			a.status = d_status;
 			a.defer = 1;
 			a.ev_list = nullptr;
 			a.deferred = (u32*)c->deferred.p;
 			a.n_deferred = d_ndef;
-			HIP_TRY(c, hipEventRecord(c->ev[3], s));
+			HIP_TRY(c, hipMemsetAsync(d_ndef, 0, 4, sB));
+			HIP_TRY(c, hipEventRecord(c->ev[3], sB));
 			// pass 1: every event, indel sweeps postponed
-			hipLaunchKernelGGL(k_machine<false>, dim3((unsigned)blocks), dim3(MACHINE_TPB), dyn_lds, s, a);
+			hipLaunchKernelGGL(k_machine<false>, dim3((unsigned)blocks), dim3(MACHINE_TPB), dyn_lds, sB, a);
 			HIP_TRY(c, hipGetLastError());
 			u32 h_tail[4] = { 0, 0, 0, 0 };
-			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, s));
-			HIP_TRY(c, hipEventRecord(c->ev[5], s));
-			HIP_TRY(c, hipStreamSynchronize(s));
+			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+			HIP_TRY(c, hipEventRecord(c->ev[5], sB));
+			HIP_TRY(c, hipStreamSynchronize(sB));
 			const u32 n_def = h_tail[3];
-			r->st.events_deferred = n_def;
-			if (n_def > 0 && h_tail[2] == 0) {
-				// pass 2: only the events that need a sweep, so whole waves are busy with sweeps
+			deferred_total += n_def;
+			status = h_tail[2];
+			if (n_def > 0 && status == 0) {
+				// pass 2: one wavefront per event that needs an indel sweep
 				a.defer = 0;
 				a.ev_list = (const u32*)c->deferred.p;
 				a.n_events = n_def;
-				// one wavefront per deferred event, 4 per workgroup; persistent grid
 				const u64 want2 = ((u64)n_def + 3) / 4;
 				const u64 cap2 = (u64)c->cu_count * 8;
 				const u64 b2 = want2 < cap2 ? want2 : cap2;
 				const size_t dyn2 = a.win_in_lds ? (size_t)a.win_bytes * 4 : 0;
-				hipLaunchKernelGGL(k_machine<true>, dim3((unsigned)b2), dim3(MACHINE_TPB), dyn2, s, a);
+				hipLaunchKernelGGL(k_machine<true>, dim3((unsigned)b2), dim3(MACHINE_TPB), dyn2, sB, a);
 				HIP_TRY(c, hipGetLastError());
 			}
-			HIP_TRY(c, hipEventRecord(c->ev[4], s));
-			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, s));
-			HIP_TRY(c, hipStreamSynchronize(s));
+			HIP_TRY(c, hipEventRecord(c->ev[4], sB));
+			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+			HIP_TRY(c, hipStreamSynchronize(sB));
+			status = h_tail[2];
+			float p1 = 0.f, p2 = 0.f;
+			(void)hipEventElapsedTime(&p1, c->ev[3], c->ev[5]);
+			(void)hipEventElapsedTime(&p2, c->ev[5], c->ev[4]);
+			ms_machine += p1 + p2;
 			if (getenv("NTEDIT_HIP_DEBUG")) {
-				float p1 = 0.f, p2 = 0.f;
-				(void)hipEventElapsedTime(&p1, c->ev[3], c->ev[5]);
-				(void)hipEventElapsedTime(&p2, c->ev[5], c->ev[4]);
-				fprintf(stderr, "[ntedit_hip] events %llu deferred %u pass1 %.3f ms pass2 %.3f ms arena chunks %u status %u window %u\n",
-				        (unsigned long long)n_events, n_def, p1, p2, h_tail[0], h_tail[2], c->dp.node_window);
+				fprintf(
+				    stderr,
+				    "[ntedit_hip] chunk %zu/%zu contigs %u-%u events %llu deferred %u pass1 %.3f ms pass2 %.3f ms arena %u "
+				    "status %u window %u\n",
+				    j + 1, n_ch, ch.c0, ch.c1, (unsigned long long)n_ev, n_def, p1, p2, h_tail[0], status, c->dp.node_window);
 			}
-			const u32 used = h_tail[0], status = h_tail[2];
-			if (status == 0) {
-				const u64 used_chunks = used < arena_chunks ? used : arena_chunks;
-				r->arena_items = (size_t)used_chunks * CHUNK_ITEMS;
-				if ((rc = pin_take(c, r->arena_items * sizeof(Item) + 16, &r->arena_buf)) ||
-				    (rc = pin_take(c, n_events * 4 + 16, &r->first_buf))) {
-					return bail(rc);
-				}
-				if (used_chunks) {
-					HIP_TRY(c, hipMemcpyAsync(r->arena_buf.p, c->arena.p, r->arena_items * sizeof(Item), hipMemcpyDeviceToHost, s));
-				}
-				HIP_TRY(c, hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, n_events * 4, hipMemcpyDeviceToHost, s));
-				HIP_TRY(c, hipStreamSynchronize(s));
-				// keep the events that produced output, in position order (compacted in place)
-				u32* first = (u32*)r->first_buf.p;
-				size_t w = 0;
-				for (u64 i = 0; i < n_events; i++) {
-					if (first[i] != NONE32) {
-						first[w++] = first[i];
-					}
-				}
-				r->n_ev_first = w;
-				break;
-			}
-			if (attempt >= 4) {
-				return bail(fail(c, NTEDIT_E_OVERFLOW, "event machine ran out of room (status %u)", status));
-			}
-			if (status & EV_ARENA_FULL) {
-				arena_chunks *= 4;
-			}
-			if (status & EV_OVERFLOW) {
-				c->dp.node_window *= 2;
-			}
+			ev_total += n_ev;
 		}
-	} else {
-		HIP_TRY(c, hipEventRecord(c->ev[4], s));
-		HIP_TRY(c, hipStreamSynchronize(s));
+		HIP_TRY(c, hipStreamSynchronize(sA));
+		HIP_TRY(c, hipStreamSynchronize(sB));
+		if (status == 0) {
+			u32 h_tail[4] = { 0, 0, 0, 0 };
+			HIP_TRY(c, hipMemcpy(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost));
+			const u64 used_chunks = h_tail[0] < arena_chunks ? h_tail[0] : arena_chunks;
+			r->st.absent_kmers = absent_total;
+			r->st.events = ev_total;
+			r->st.events_deferred = deferred_total;
+			r->arena_items = (size_t)used_chunks * CHUNK_ITEMS;
+			if ((rc = pin_take(c, r->arena_items * sizeof(Item) + 16, &r->arena_buf)) ||
+			    (rc = pin_take(c, ev_total * 4 + 16, &r->first_buf))) {
+				return bail(rc);
+			}
+			if (used_chunks) {
+				HIP_TRY(c, hipMemcpyAsync(r->arena_buf.p, c->arena.p, r->arena_items * sizeof(Item), hipMemcpyDeviceToHost, sB));
+			}
+			if (ev_total) {
+				HIP_TRY(c, hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));
+			}
+			HIP_TRY(c, hipEventRecord(c->ev[4], sB));
+			HIP_TRY(c, hipStreamSynchronize(sB));
+			// keep the events that produced output, in position order (compacted in place)
+			u32* first = (u32*)r->first_buf.p;
+			size_t w = 0;
+			for (u64 i = 0; i < ev_total; i++) {
+				if (first[i] != NONE32) {
+					first[w++] = first[i];
+				}
+			}
+			r->n_ev_first = w;
+			// timings: screening = sum of its launches (they may overlap machine kernels)
+			float ms_screen = 0.f;
+			const size_t n_scr = pipelined ? n_ch : 1;
+			for (size_t j = 0; j < n_scr; j++) {
+				float t = 0.f;
+				(void)hipEventElapsedTime(&t, c->chunk_ev[2 * j], c->chunk_ev[2 * j + 1]);
+				ms_screen += t;
+			}
+			r->st.ms_screen = ms_screen;
+			r->st.screen_launches = (uint32_t)n_scr;
+			r->st.ms_machine = ms_machine;
+			(void)ms_extract;
+			r->st.ms_extract = 0.f;
+			HIP_TRY(c, hipEventElapsedTime(&r->st.ms_total, c->ev[0], c->ev[4]));
+			c->last_ms = ms_screen;
+			break;
+		}
+		if (attempt >= 4) {
+			return bail(fail(c, NTEDIT_E_OVERFLOW, "event machine ran out of room (status %u)", status));
+		}
+		if (status & EV_ARENA_FULL) {
+			arena_chunks *= 4;
+		}
+		if (status & EV_OVERFLOW) {
+			c->dp.node_window *= 2;
+		}
 	}
-	HIP_TRY(c, hipEventElapsedTime(&r->st.ms_screen, c->ev[0], c->ev[1]));
-	HIP_TRY(c, hipEventElapsedTime(&r->st.ms_extract, c->ev[1], c->ev[2]));
-	HIP_TRY(c, hipEventElapsedTime(&r->st.ms_machine, c->ev[3], c->ev[4]));
-	HIP_TRY(c, hipEventElapsedTime(&r->st.ms_total, c->ev[0], c->ev[4]));
-	c->last_ms = r->st.ms_screen;
 	return 0;
 }
 

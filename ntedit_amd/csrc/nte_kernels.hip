@@ -45,11 +45,13 @@ k_screen(
     DevParams p,
     const u64* __restrict__ tabs,
     u64* __restrict__ bitmap,
-    u64 n_words)
+    u64 n_words,
+    u64 first_tile)
 {
 	__shared__ u64 s_tab[TAB_WORDS];
 	__shared__ u8 s_lut[256];
 	__shared__ __attribute__((aligned(16))) u8 s_codes[SCREEN_LDS_BYTES];
+	extern __shared__ u8 s_occupancy_pad[]; // launch-time LDS pad: leaves CU room for k_machine
 
 	const u32 tid = threadIdx.x;
 	if (tid < TAB_WORDS) {
@@ -64,7 +66,7 @@ k_screen(
 	}
 	__syncthreads();
 
-	const u64 tile_base = (u64)blockIdx.x * SCREEN_TILE;
+	const u64 tile_base = (first_tile + blockIdx.x) * SCREEN_TILE;
 	const u32 k = p.k;
 	// ---- stage the tile: 16-byte chunks, translated to codes
 	const u32 n_chunks = (SCREEN_TILE + k - 1 + 15) / 16;
@@ -203,7 +205,7 @@ k_screen(
 		}
 	}
 	if (!INSERT) {
-		const u64 w = (u64)blockIdx.x * SCREEN_TPB + tid;
+		const u64 w = (first_tile + blockIdx.x) * SCREEN_TPB + tid;
 		if (w < n_words) {
 			bitmap[w] = bits;
 		}
@@ -474,6 +476,23 @@ k_bin_probe(
 }
 
 // ------------------------------------------------------------ event starts
+// bits of word w whose position lies in [pos_lo, pos_hi)
+__device__ __forceinline__ u64
+range_mask(u64 w, u64 pos_lo, u64 pos_hi)
+{
+	const u64 b = w * 64;
+	u64 m = ~0ULL;
+	if (b < pos_lo) {
+		const u64 d = pos_lo - b;
+		m = d >= 64 ? 0 : (m << d);
+	}
+	if (b + 64 > pos_hi) {
+		const u64 d = pos_hi > b ? pos_hi - b : 0;
+		m &= d >= 64 ? ~0ULL : ((1ULL << d) - 1);
+	}
+	return m;
+}
+
 __device__ __forceinline__ u64
 start_mask(const u64* __restrict__ bitmap, u64 w, u64 grid_lo, u32 grid)
 {
@@ -492,11 +511,16 @@ start_mask(const u64* __restrict__ bitmap, u64 w, u64 grid_lo, u32 grid)
 
 constexpr int ST_TPB = 256;
 
+// A range of the batch [pos_lo, pos_hi) (one pipeline chunk = whole contigs) is turned into
+// its ordered event list: words [w0, w0 + gridDim*256).
 // counters[0] += absent k-mers ; block_counts[b] = starts in block b
 __global__ __launch_bounds__(ST_TPB) void
 k_count_starts(
     const u64* __restrict__ bitmap,
-    u64 n_words,
+    u64 w0,
+    u64 w1,
+    u64 pos_lo,
+    u64 pos_hi,
     u64 grid_lo,
     u32 grid,
     u32* __restrict__ block_counts,
@@ -504,11 +528,12 @@ k_count_starts(
 {
 	__shared__ u32 s_cnt[ST_TPB / 64];
 	__shared__ u32 s_abs[ST_TPB / 64];
-	const u64 w = (u64)blockIdx.x * ST_TPB + threadIdx.x;
+	const u64 w = w0 + (u64)blockIdx.x * ST_TPB + threadIdx.x;
 	u32 c = 0, a = 0;
-	if (w < n_words) {
-		c = __popcll(start_mask(bitmap, w, grid_lo, grid));
-		a = __popcll(bitmap[w]);
+	if (w < w1) {
+		const u64 rm = range_mask(w, pos_lo, pos_hi);
+		c = __popcll(start_mask(bitmap, w, grid_lo, grid) & rm);
+		a = __popcll(bitmap[w] & rm);
 	}
 	for (int off = 32; off > 0; off >>= 1) {
 		c += __shfl_down(c, off, 64);
@@ -580,17 +605,20 @@ k_scan_counts(
 __global__ __launch_bounds__(ST_TPB) void
 k_write_starts(
     const u64* __restrict__ bitmap,
-    u64 n_words,
+    u64 w0,
+    u64 w1,
+    u64 pos_lo,
+    u64 pos_hi,
     u64 grid_lo,
     u32 grid,
     const unsigned long long* __restrict__ block_offsets,
     u64* __restrict__ events)
 {
 	__shared__ u32 s_scan[ST_TPB];
-	const u64 w = (u64)blockIdx.x * ST_TPB + threadIdx.x;
+	const u64 w = w0 + (u64)blockIdx.x * ST_TPB + threadIdx.x;
 	u64 m = 0;
-	if (w < n_words) {
-		m = start_mask(bitmap, w, grid_lo, grid);
+	if (w < w1) {
+		m = start_mask(bitmap, w, grid_lo, grid) & range_mask(w, pos_lo, pos_hi);
 	}
 	const u32 c = __popcll(m);
 	s_scan[threadIdx.x] = c;

@@ -174,3 +174,28 @@ def test_polish_with_binned_screen(tmp_path, ci, oracle_build):
         pol.close()
     assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "g_changes.tsv"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "g_edited.fa"), shallow=False)
+
+
+@pytest.mark.parametrize("ci", [0, 1, 9, 10, 20, 22])
+def test_polish_chunk_pipeline(tmp_path, ci, oracle_build, monkeypatch):
+    """many small pipeline chunks (screening of chunk j+1 overlaps the event machine of chunk j
+    on a second stream) must give the same bytes as one chunk"""
+    monkeypatch.setenv("NTEDIT_HIP_CHUNK_BYTES", "50000")
+    case_kw, par_kw = H.PARITY_CONFIGS[ci]
+    case_kw = dict(case_kw, contigs=7, n=30000)
+    case = H.make_case(str(tmp_path), 6000 + ci, **case_kw)
+    hp = H.default_params(**par_kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), case["rep"])
+    pol = _fresh()
+    try:
+        _load_filters(pol, case)
+        pol.set_params(_hip_params(**par_kw))
+        st = pol.polish_records(H.read_fasta(case["draft"]), str(tmp_path / "g"))
+        assert st.screen_launches >= 4
+        # and again on the warm context (buffers already sized)
+        pol.polish_records(H.read_fasta(case["draft"]), str(tmp_path / "g2"))
+    finally:
+        pol.close()
+    for g in ("g", "g2"):
+        assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / (g + "_changes.tsv")), shallow=False)
+        assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / (g + "_edited.fa")), shallow=False)

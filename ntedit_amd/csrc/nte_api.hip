@@ -218,6 +218,9 @@ refresh_params(ntedit_hip_ctx* c)
 	if (rc) {
 		return fail(c, rc, "unsupported parameter combination (k=%u h=%u)", f.k, f.hash_num);
 	}
+	if (const char* e = getenv("NTEDIT_HIP_MACHINE_DEBUG")) {
+		c->dp.debug_stop = (u32)atoi(e); // timing ablations; results are NOT valid
+	}
 	if (!c->d_tab) {
 		HIP_TRY(c, hipMalloc((void**)&c->d_tab, TAB_WORDS * sizeof(u64)));
 	}
@@ -1162,6 +1165,7 @@ ntedit_hip_polish_batch(
 			}
 			MachineArgs a;
 			a.seq = d_seq;
+			a.n_bytes = n;
 			a.offsets = (const u64*)c->offs.p;
 			a.lens = (const u32*)c->lens.p;
 			a.n_contigs = n_contigs;
@@ -1177,7 +1181,7 @@ ntedit_hip_polish_batch(
 			a.ws_ov_chr = (u8*)c->ws_ov_chr.p;
 			a.ws_prev = (u8*)c->ws_prev.p;
 			a.ws_lps = (int16_t*)c->ws_lps.p;
-			a.win_bytes = 2 * c->dp.k + c->dp.max_deletions + 8;
+			a.win_bytes = 2 * c->dp.k + c->dp.max_deletions + 8 + 32; // Machine::win_bytes() + slack
 			a.win_in_lds = (size_t)a.win_bytes * MACHINE_TPB <= 40 * 1024 ? 1 : 0;
 			a.ws_win = nullptr;
 			if (!a.win_in_lds) {

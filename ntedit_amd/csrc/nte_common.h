@@ -12,8 +12,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define NTE_HD __host__ __device__ __forceinline__
+#define NTE_UNROLL _Pragma("unroll")
 #else
 #define NTE_HD inline
+#define NTE_UNROLL
 #endif
 
 namespace nte {
@@ -233,6 +235,8 @@ struct DevParams
 	u32 thr_missing, thr_edit, thr_edit_del;
 	u32 start_grid;    // extra event start every start_grid positions inside an absent run
 	u32 node_window;   // live rope nodes kept per event thread
+	u32 debug_stop;    // timing ablations only (NTEDIT_HIP_MACHINE_DEBUG): 1 seed, 2 step 2, 4 first position
+	u32 pad0;
 	u64 mul[MAX_HASHES]; // mul[i] = i ^ (k * MULTISEED), i >= 1
 };
 

@@ -644,6 +644,7 @@ k_write_starts(
 struct MachineArgs
 {
 	const u8* seq;
+	u64 n_bytes;        // batch bytes
 	const u64* offsets; // start of every contig in the batch
 	const u32* lens;
 	u32 n_contigs;
@@ -745,6 +746,7 @@ k_machine(MachineArgs a)
 		env.contig = lo;
 		env.gbase = a.offsets[lo];
 		env.seq = a.seq + env.gbase;
+		env.batch_end = a.seq + a.n_bytes;
 		env.len = a.lens[lo];
 		const u32 start = (u32)(g - env.gbase);
 		u32 fc = NONE32;

@@ -47,6 +47,7 @@ extern WorkCounters g_wc;
 struct EventEnv
 {
 	const u8* seq;  // contig bases
+	const u8* batch_end; // one past the last byte of the batch buffer
 	u32 len;
 	u32 contig;
 	u64 gbase;      // global index of seq[0] in the batch (bitmap coordinates)
@@ -125,6 +126,9 @@ struct Machine
 	u32 flags;
 	// window of the failing position (see fill_window)
 	bool win_ok;
+	bool wc_valid;      // the window holds a clean stretch of draft codes starting at wc_pos0
+	u32 wc_pos0, wc_len;
+	u32 win_off;        // offset of the current failing position inside that stretch
 
 	NTE_HD
 	Machine(const EventEnv& env)
@@ -449,6 +453,158 @@ struct Machine
 	present_solid(const HashState& s) const
 	{
 		return in_bloom(s) && solid(s);
+	}
+
+	// Membership of up to G k-mers at once.  The h probes of ONE k-mer depend on each other
+	// only through the early exit, which has no side effect; probing level by level keeps
+	// G independent gathers in flight instead of one (the event machine is bound by memory
+	// latency, not bandwidth).  All array indices are compile-time constants so the group
+	// lives in registers.  b[i] = canonical hash fh+rh; returns a bit mask of members.
+	template<int G>
+	NTE_HD u32
+	probe_group(const Filter& f, const u64 (&b)[G], u32 n) const
+	{
+		u32 alive = (1u << n) - 1;
+		NTE_COUNT(probes, n);
+		for (u32 h = 0; h < f.hash_num && alive; h++) {
+			u8 byte[G];
+			u8 sh[G];
+			NTE_UNROLL
+			for (int i = 0; i < G; i++) {
+				byte[i] = 0xFF;
+				sh[i] = 0;
+				if ((alive >> i) & 1) {
+					const u64 sl = filter_slot(f, hash_extend(b[i], p, h));
+					byte[i] = f.data[sl >> 3];
+					sh[i] = (u8)(sl & 7);
+				}
+			}
+			NTE_UNROLL
+			for (int i = 0; i < G; i++) {
+				if (!((byte[i] >> sh[i]) & 1)) {
+					alive &= ~(1u << i);
+				}
+			}
+		}
+		return alive;
+	}
+
+	// present in the primary filter and (solid_check) not in the secondary one
+	template<int G>
+	NTE_HD u32
+	present_group(const u64 (&b)[G], u32 n, bool solid_check) const
+	{
+		u32 m = probe_group<G>(e.bloom, b, n);
+		if (solid_check && p.secbf && m) {
+			// the secondary filter only matters for k-mers that are present
+			u32 r = 0;
+			for (u32 h = 0; h < e.rep.hash_num; h++) {
+				(void)h;
+			}
+			u32 alive = m;
+			for (u32 h = 0; h < e.rep.hash_num && alive; h++) {
+				u8 byte[G];
+				u8 sh[G];
+				NTE_UNROLL
+				for (int i = 0; i < G; i++) {
+					byte[i] = 0xFF;
+					sh[i] = 0;
+					if ((alive >> i) & 1) {
+						const u64 sl = filter_slot(e.rep, hash_extend(b[i], p, h));
+						byte[i] = e.rep.data[sl >> 3];
+						sh[i] = (u8)(sl & 7);
+					}
+				}
+				NTE_UNROLL
+				for (int i = 0; i < G; i++) {
+					if (!((byte[i] >> sh[i]) & 1)) {
+						alive &= ~(1u << i);
+					}
+				}
+			}
+			r = alive; // in the secondary filter -> not solid
+			m &= ~r;
+		}
+		return m;
+	}
+
+	NTE_HD static u32
+	popc32(u32 x)
+	{
+		u32 c = 0;
+		while (x) {
+			x &= x - 1;
+			c++;
+		}
+		return c;
+	}
+
+	// Walks rolls kk0..last (rf performs roll number kk on the hash state and returns false to
+	// abort), gathers the subset k-mers (kk % jump == 0) in groups of G and probes each group
+	// at once.  extra: a k-mer counted ahead of the walk (the changed k-mer of a deletion).
+	// need_present / need_absent (0 = off): give up as soon as the count can no longer reach it.
+	struct SubsetResult
+	{
+		u32 present, total;
+		bool aborted, gave_up;
+	};
+
+	template<int G, typename RollFn>
+	NTE_HD SubsetResult
+	subset_scan(HashState ts, u32 kk0, u32 last, bool solid_check, bool have_extra, u64 extra, u32 need_present, u32 need_absent, RollFn rf) const
+	{
+		SubsetResult r;
+		r.present = 0;
+		r.total = 0;
+		r.aborted = false;
+		r.gave_up = false;
+		u32 kk = kk0;
+		while (true) {
+			u64 b[G];
+			u32 nb = 0;
+			NTE_UNROLL
+			for (int u = 0; u < G; u++) {
+				b[u] = 0;
+			}
+			if (have_extra) {
+				b[0] = extra;
+				nb = 1;
+				have_extra = false;
+			}
+			NTE_UNROLL
+			for (int u = 0; u < G; u++) {
+				if (nb == (u32)u) {
+					while (kk <= last) {
+						if (!rf(kk, ts)) {
+							r.aborted = true;
+							return r;
+						}
+						const bool is_sub = (kk % p.jump) == 0;
+						kk++;
+						if (is_sub) {
+							b[u] = ts.fh + ts.rh;
+							nb = (u32)u + 1;
+							break;
+						}
+					}
+				}
+			}
+			if (nb == 0) {
+				break;
+			}
+			r.present += popc32(present_group<G>(b, nb, solid_check));
+			r.total += nb;
+			if (kk > last) {
+				break;
+			}
+			const u32 left = probes_left(kk - 1, last);
+			if ((need_present && r.present + left < need_present) ||
+			    (need_absent && (r.total - r.present) + left < need_absent)) {
+				r.gave_up = true;
+				break;
+			}
+		}
+		return r;
 	}
 
 	NTE_HD void
@@ -782,16 +938,28 @@ struct Machine
 		return p.k + p.max_deletions + 1;
 	}
 
+	// window storage: win_bytes() bytes.  After a "clean" fill it simply holds the codes of
+	// the draft from wc_pos0 on (O and I are the same stretch of sequence, I = O shifted by
+	// k), so the following failing positions of the same absent run reuse it with an offset
+	// instead of being re-read; the extra WIN_AHEAD codes make that possible.
+	static constexpr u32 WIN_AHEAD = 32;
+
+	NTE_HD u32
+	win_bytes() const
+	{
+		return 2 * p.k + p.max_deletions + 1 + WIN_AHEAD;
+	}
+
 	NTE_HD u8
 	win_o(u32 i) const
 	{
-		return e.win[(u64)i * e.win_stride];
+		return e.win[(u64)(win_off + i) * e.win_stride];
 	}
 
 	NTE_HD u8
 	win_i(u32 i) const
 	{
-		return e.win[(u64)(p.k + i) * e.win_stride];
+		return e.win[(u64)(win_off + p.k + i) * e.win_stride];
 	}
 
 	NTE_HD bool
@@ -805,13 +973,46 @@ struct Machine
 		// clean fast fill: both cursors in one position node that extends far enough
 		if (h_node == t_node && hn.type == 0 && !tmp_on && n_ov == 0 && t_seq_i == h_seq_i + p.k - 1 &&
 		    (u64)t_seq_i + K <= hn.e_pos && h_seq_i >= hn.s_pos) {
-			const u8* s = e.seq + h_seq_i;
-			for (u32 i = 0; i < p.k + K; i++) {
-				// O[0..k) = s[0..k), I[0..K) = s[k..k+K): contiguous in both arrays
-				e.win[(u64)i * e.win_stride] = char_code(s[i]);
+			if (wc_valid && h_seq_i >= wc_pos0 && h_seq_i + p.k + K <= wc_pos0 + wc_len) {
+				win_off = h_seq_i - wc_pos0; // still covered by the last clean fill
+				return true;
 			}
+			// read the draft in aligned 8-byte words (a byte loop costs one load per base)
+			u32 want = p.k + K + WIN_AHEAD;
+			const u64 room = (u64)hn.e_pos + 1 - h_seq_i;
+			if (want > room) {
+				want = (u32)room;
+			}
+			const u64 g0 = e.gbase + h_seq_i; // byte index in the batch buffer
+			const u8* base = e.seq - e.gbase; // batch buffer start (16-byte aligned)
+			const u64 a0 = g0 & ~7ULL;
+			u32 filled = 0;
+			u32 skip = (u32)(g0 - a0);
+			for (u64 a = a0; filled < want; a += 8) {
+				u64 w = 0;
+				if (base + a + 8 <= e.batch_end) {
+					w = *reinterpret_cast<const u64*>(base + a);
+				} else {
+					for (u32 b = 0; b < 8 && base + a + b < e.batch_end; b++) {
+						w |= (u64)base[a + b] << (8 * b);
+					}
+				}
+				w >>= 8 * skip;
+				for (u32 b = skip; b < 8 && filled < want; b++) {
+					e.win[(u64)filled * e.win_stride] = char_code((u8)(w & 0xFF));
+					w >>= 8;
+					filled++;
+				}
+				skip = 0;
+			}
+			wc_valid = true;
+			wc_pos0 = h_seq_i;
+			wc_len = want;
+			win_off = 0;
 			return true;
 		}
+		wc_valid = false;
+		win_off = 0;
 		u32 th = h_seq_i, tt = t_seq_i, thn = h_node, ttn = t_node;
 		u8 co = 0, ci = 0;
 		for (u32 i = 0; i < K; i++) {
@@ -846,19 +1047,12 @@ struct Machine
 		NTE_COUNT(del_cands, 1);
 		HashState ts = hs;
 		hash_changelast(ts, e.tab, draft_code, win_i(num_del - 1));
-		u32 cp = present_solid(ts) ? 1 : 0;
-		const u32 last = p.k - 2;
-		for (u32 kk = 1; kk <= last; kk++) {
-			hash_roll(ts, e.tab, win_o(kk - 1), win_i(num_del + kk - 1));
-			if (kk % p.jump == 0) {
-				if (present_solid(ts)) {
-					cp++;
-				} else if (cp + probes_left(kk, last) < p.thr_edit_del) {
-					return 0; // cannot reach the threshold any more: rejected either way
-				}
-			}
-		}
-		return cp >= p.thr_edit_del ? cp : 0;
+		const SubsetResult r = subset_scan<8>(
+		    ts, 1, p.k - 2, true, true, ts.fh + ts.rh, p.thr_edit_del, 0, [&](u32 kk, HashState& t) {
+			    hash_roll(t, e.tab, win_o(kk - 1), win_i(num_del + kk - 1));
+			    return true;
+		    });
+		return (!r.gave_up && r.present >= p.thr_edit_del) ? r.present : 0;
 	}
 
 	// fast form of the insertion support count (ntedit.cpp:1600-1645);
@@ -869,27 +1063,20 @@ struct Machine
 		NTE_COUNT(ins_cands, 1);
 		HashState ts = hs;
 		hash_changelast(ts, e.tab, draft_code, char_code(ins[0]));
-		u32 cp = 0;
-		const u32 last = p.k - 2;
-		for (u32 kk = 0; kk <= last; kk++) {
-			u8 in;
-			if (kk + 1 < m) {
-				in = char_code(ins[kk + 1]);
-			} else if (kk + 1 == m) {
-				in = draft_code;
-			} else {
-				in = win_i(kk - m);
-			}
-			hash_roll(ts, e.tab, win_o(kk), in);
-			if (kk % p.jump == 0) {
-				if (present_solid(ts)) {
-					cp++;
-				} else if (cp + probes_left(kk, last) < p.thr_edit) {
-					return 0;
-				}
-			}
-		}
-		return cp;
+		const SubsetResult r =
+		    subset_scan<8>(ts, 0, p.k - 2, true, false, 0, p.thr_edit, 0, [&](u32 kk, HashState& t) {
+			    u8 in;
+			    if (kk + 1 < m) {
+				    in = char_code(ins[kk + 1]);
+			    } else if (kk + 1 == m) {
+				    in = draft_code;
+			    } else {
+				    in = win_i(kk - m);
+			    }
+			    hash_roll(t, e.tab, win_o(kk), in);
+			    return true;
+		    });
+		return r.gave_up ? 0 : r.present;
 	}
 
 	// ntedit.cpp:1451-1545; returns the support (0 = rejected)
@@ -1324,22 +1511,18 @@ struct Machine
 		bool do_not_fix = false;
 		win_ok = fill_window();
 		if (win_ok) {
-			const u32 last = p.k - 1;
-			for (u32 k = 0; k <= last; k++) {
-				const u8 in = win_i(k);
-				hash_roll(ts, e.tab, win_o(k), in);
-				if (in == CODE_BAD) {
-					do_not_fix = true;
-					break;
-				}
-				if (k % p.jump == 0) {
-					if (!in_bloom(ts)) {
-						check_missing++;
-					} else if (check_missing + probes_left(k, last) < p.thr_missing) {
-						return; // the confirmation can no longer succeed
-					}
-				}
+			const SubsetResult r =
+			    subset_scan<8>(ts, 0, p.k - 1, false, false, 0, 0, p.thr_missing, [&](u32 k, HashState& t) {
+				    const u8 in = win_i(k);
+				    hash_roll(t, e.tab, win_o(k), in);
+				    return in != CODE_BAD;
+			    });
+			if (r.aborted) {
+				do_not_fix = true;
+			} else if (r.gave_up) {
+				return; // the confirmation can no longer succeed
 			}
+			check_missing = r.total - r.present;
 		} else
 		for (u32 k = 0; k < p.k && th < e.len; k++) {
 			if (roll(th, tt, thn, ttn, char_out, char_in)) {
@@ -1356,7 +1539,7 @@ struct Machine
 				break;
 			}
 		}
-		if (do_not_fix || check_missing < p.thr_missing) {
+		if (do_not_fix || check_missing < p.thr_missing || p.debug_stop == 2) {
 			return;
 		}
 
@@ -1399,17 +1582,12 @@ struct Machine
 				tmp_on = false;
 				const u8 sub_code = char_code(sub_base);
 				const u32 last = p.k - 1;
-				for (u32 k = 0; k <= last; k++) {
-					hash_roll(ts, e.tab, k == last ? sub_code : win_o(k), win_i(k));
-					if (k % p.jump == 0) {
-						if (present_solid(ts)) {
-							check_present++;
-						} else if (check_present + probes_left(k, last) < p.thr_edit) {
-							check_present = 0;
-							break;
-						}
-					}
-				}
+				const SubsetResult r =
+				    subset_scan<8>(ts, 0, last, true, false, 0, p.thr_edit, 0, [&](u32 k, HashState& t) {
+					    hash_roll(t, e.tab, k == last ? sub_code : win_o(k), win_i(k));
+					    return true;
+				    });
+				check_present = r.gave_up ? 0 : r.present;
 			} else
 			for (u32 k = 0; k < p.k && th < e.len && tt < e.len; k++) {
 				if (roll(th, tt, thn, ttn, char_out, char_in)) {
@@ -1521,6 +1699,10 @@ struct Machine
 		tmp_chr = 0;
 		last_sub_pos = -1;
 		win_ok = false;
+		wc_valid = false;
+		wc_pos0 = 0;
+		wc_len = 0;
+		win_off = 0;
 		first_chunk = cur_chunk = NONE32;
 		fill = 0;
 		flags = 0;
@@ -1548,6 +1730,10 @@ struct Machine
 		u8 char_in = e.seq[t_seq_i];
 		u8 char_out = 0;
 
+		if (p.debug_stop == 1) {
+			cover_end = e.len;
+			return;
+		}
 		bool first = true;
 		while (true) {
 			if ((u64)h_seq_i + p.k - 1 >= e.len) {
@@ -1573,6 +1759,10 @@ struct Machine
 			first = false;
 			if (missing) {
 				process_missing(char_in);
+			}
+			if (p.debug_stop >= 2) {
+				cover_end = e.len;
+				break;
 			}
 			// advance; skip over k-mers containing a non-accepted base (ntedit.cpp:2119-2138)
 			bool ended = false;

@@ -124,7 +124,7 @@ hostsim_polish(
 	std::vector<Node> nodes(p.node_window);
 	std::vector<u32> ov_pos(p.node_window);
 	std::vector<u8> ov_chr(p.node_window);
-	std::vector<u8> win(2 * p.k + p.max_deletions + 8);
+	std::vector<u8> win(2 * p.k + p.max_deletions + 8 + 32);
 	std::vector<u8> prev(p.node_window);
 	std::vector<int16_t> lps(p.node_window);
 	std::vector<u32> ev_first;
@@ -137,6 +137,7 @@ hostsim_polish(
 		}
 		EventEnv env;
 		env.seq = (const u8*)bases + offsets[ci];
+		env.batch_end = (const u8*)bases + n;
 		env.len = lens[ci];
 		env.contig = ci;
 		env.gbase = offsets[ci];

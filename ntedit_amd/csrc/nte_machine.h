@@ -1510,7 +1510,23 @@ struct Machine
 		u32 check_missing = 0;
 		bool do_not_fix = false;
 		win_ok = fill_window();
-		if (win_ok) {
+		if (win_ok && wc_valid && is_clean()) {
+			// Clean state: the k-mers of the confirmation subset are un-edited draft k-mers,
+			// i.e. exactly what the screening pass already answered -- read their bits
+			// (bit = all bases accepted AND absent) instead of probing the filter again.
+			for (u32 k = 0; k < p.k; k++) {
+				if (win_i(k) == CODE_BAD) {
+					do_not_fix = true;
+					break;
+				}
+			}
+			if (!do_not_fix) {
+				const u64 g = e.gbase + h_seq_i + 1;
+				for (u32 k = 0; k < p.k; k += p.jump) {
+					check_missing += bit_absent(e.bitmap, g + k) ? 1u : 0u;
+				}
+			}
+		} else if (win_ok) {
 			const SubsetResult r =
 			    subset_scan<8>(ts, 0, p.k - 1, false, false, 0, 0, p.thr_missing, [&](u32 k, HashState& t) {
 				    const u8 in = win_i(k);
@@ -1756,13 +1772,22 @@ struct Machine
 			} else {
 				missing = !in_bloom(hs);
 			}
+			const bool was_first = first;
 			first = false;
 			if (missing) {
 				process_missing(char_in);
 			}
-			if (p.debug_stop >= 2) {
+			if (p.debug_stop >= 2 && p.debug_stop < 8) {
 				cover_end = e.len;
 				break;
+			}
+			if (p.debug_stop >= 8 && was_first) {
+				// 8: keep only events whose first position made an edit; 16: only the others
+				const bool edited = last_sub_pos >= 0 || rope_touched;
+				if ((p.debug_stop == 8 && !edited) || (p.debug_stop == 16 && edited)) {
+					cover_end = e.len;
+					break;
+				}
 			}
 			// advance; skip over k-mers containing a non-accepted base (ntedit.cpp:2119-2138)
 			bool ended = false;

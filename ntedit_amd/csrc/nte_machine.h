@@ -129,6 +129,9 @@ struct Machine
 	bool wc_valid;      // the window holds a clean stretch of draft codes starting at wc_pos0
 	u32 wc_pos0, wc_len;
 	u32 win_off;        // offset of the current failing position inside that stretch
+	// presence of the next k-mers while the window still overlaps an edit (see build_lookahead)
+	u32 la_mask, la_n, la_i;
+	bool la_off;
 
 	NTE_HD
 	Machine(const EventEnv& env)
@@ -1011,21 +1014,97 @@ struct Machine
 			win_off = 0;
 			return true;
 		}
+		// general case (window overlaps edits): walk the rope, copying the stretches that
+		// lie in position nodes straight from the draft (overlay applied afterwards)
 		wc_valid = false;
 		win_off = 0;
-		u32 th = h_seq_i, tt = t_seq_i, thn = h_node, ttn = t_node;
-		u8 co = 0, ci = 0;
-		for (u32 i = 0; i < K; i++) {
-			if (th >= e.len || tt >= e.len) {
+		if (tmp_on) {
+			return false;
+		}
+		if (!collect_codes(h_seq_i, h_node, false, p.k, 0)) {
+			return false;
+		}
+		return collect_codes(t_seq_i, t_node, true, K, p.k);
+	}
+
+	// Writes `count` character codes of the edited sequence into the window at dst..:
+	// starting AT cursor (pos, node) or, when after_cursor, with the character behind it --
+	// the characters roll() would deliver.  false if the rope ends first (contig end, unset
+	// slot), in which case the caller falls back to the reference-shaped code path.
+	NTE_HD bool
+	collect_codes(u32 pos, u32 node, bool after_cursor, u32 count, u32 dst)
+	{
+		u32 done = 0;
+		bool skip_one = after_cursor;
+		while (done < count) {
+			const Node n = nget(node);
+			if (node >= nsize || pos >= e.len) {
 				return false;
 			}
-			if (!roll(th, tt, thn, ttn, co, ci)) {
+			if (n.type == 1) {
+				if (!skip_one) {
+					e.win[(u64)(dst + done) * e.win_stride] = char_code(n.c);
+					done++;
+				}
+				skip_one = false;
+				node++;
+				const Node nx = nget(node);
+				if (nx.type == 0) {
+					pos = nx.s_pos;
+				}
+				continue;
+			}
+			if (n.type != 0 || pos < n.s_pos || pos > n.e_pos) {
 				return false;
 			}
-			if (i < p.k) {
-				e.win[(u64)i * e.win_stride] = char_code(co);
+			u32 from = pos;
+			if (skip_one) {
+				from++;
+				skip_one = false;
 			}
-			e.win[(u64)(p.k + i) * e.win_stride] = char_code(ci);
+			u32 avail = from <= n.e_pos ? n.e_pos - from + 1 : 0;
+			u32 take = count - done < avail ? count - done : avail;
+			if (take) {
+				const u64 g0 = e.gbase + from;
+				const u8* base = e.seq - e.gbase;
+				const u64 a0 = g0 & ~7ULL;
+				u32 filled = 0;
+				u32 skip = (u32)(g0 - a0);
+				for (u64 a = a0; filled < take; a += 8) {
+					u64 w = 0;
+					if (base + a + 8 <= e.batch_end) {
+						w = *reinterpret_cast<const u64*>(base + a);
+					} else {
+						for (u32 b = 0; b < 8 && base + a + b < e.batch_end; b++) {
+							w |= (u64)base[a + b] << (8 * b);
+						}
+					}
+					w >>= 8 * skip;
+					for (u32 b = skip; b < 8 && filled < take; b++) {
+						e.win[(u64)(dst + done + filled) * e.win_stride] = char_code((u8)(w & 0xFF));
+						w >>= 8;
+						filled++;
+					}
+					skip = 0;
+				}
+				// modified draft characters inside the copied stretch
+				for (u32 i = 0; i < n_ov; i++) {
+					const u32 op = e.ov_pos[i];
+					if (op >= from && op < from + take) {
+						e.win[(u64)(dst + done + (op - from)) * e.win_stride] = char_code(e.ov_chr[i]);
+					}
+				}
+				done += take;
+			}
+			if (done < count) {
+				// leave this node the way increment() does
+				pos = n.e_pos + 1;
+				node++;
+				const Node nx = nget(node);
+				if (nx.type == 0) {
+					pos = nx.s_pos;
+				}
+			}
 		}
 		return true;
 	}
@@ -1494,6 +1573,64 @@ struct Machine
 		return (int64_t)h_seq_i > last_sub_pos;
 	}
 
+	// After an edit the next k-1 k-mers contain the edited base(s) and have to be probed one
+	// by one as the cursors roll on (ntedit.cpp:1806 at every position).  Their hashes only
+	// depend on characters that are already known, so they are computed ahead from the
+	// window and probed together: in groups of 8 by a single thread, one k-mer per lane by a
+	// wavefront.  Bit i of la_mask = "the k-mer i rolls ahead of the cursor is present".
+	NTE_HD void
+	build_lookahead()
+	{
+		la_n = la_i = 0;
+		la_mask = 0;
+		if (!fill_window()) {
+			la_off = true; // near the contig end: probe position by position
+			return;
+		}
+		u32 L = p.k < 32 ? p.k : 32;
+		// a non-accepted character ends the stretch the main loop walks position by position
+		for (u32 i = 0; i + 1 < L; i++) {
+			if (win_i(i) == CODE_BAD) {
+				L = i + 1;
+				break;
+			}
+		}
+		if (e.wave_size > 1) {
+			const u32 lane = wave_lane();
+			bool present = false;
+			if (lane < L) {
+				HashState ts = hs;
+				for (u32 i = 0; i < lane; i++) {
+					hash_roll(ts, e.tab, win_o(i), win_i(i));
+				}
+				present = in_bloom(ts);
+			}
+			la_mask = (u32)(wave_ballot(present) & 0xFFFFFFFFull);
+			la_n = L;
+			return;
+		}
+		HashState ts = hs;
+		u32 n = 0;
+		while (n < L) {
+			u64 b[8];
+			u32 nb = 0;
+			NTE_UNROLL
+			for (int u = 0; u < 8; u++) {
+				b[u] = 0;
+				if (n + (u32)u < L) {
+					if (n + (u32)u > 0) {
+						hash_roll(ts, e.tab, win_o(n + u - 1), win_i(n + u - 1));
+					}
+					b[u] = ts.fh + ts.rh;
+					nb = (u32)u + 1;
+				}
+			}
+			la_mask |= probe_group<8>(e.bloom, b, nb) << n;
+			n += nb;
+		}
+		la_n = L;
+	}
+
 	// steps 2-5 + makeEdit for the k-mer currently under the cursors
 	NTE_HD void
 	process_missing(u8 char_in_at_t)
@@ -1719,6 +1856,8 @@ struct Machine
 		wc_pos0 = 0;
 		wc_len = 0;
 		win_off = 0;
+		la_mask = la_n = la_i = 0;
+		la_off = false;
 		first_chunk = cur_chunk = NONE32;
 		fill = 0;
 		flags = 0;
@@ -1770,12 +1909,21 @@ struct Machine
 				}
 				missing = true; // clean state: the screening bitmap already answered
 			} else {
-				missing = !in_bloom(hs);
+				if (la_i >= la_n && !la_off) {
+					build_lookahead();
+				}
+				if (la_i < la_n) {
+					missing = !((la_mask >> la_i) & 1);
+				} else {
+					missing = !in_bloom(hs);
+				}
 			}
 			const bool was_first = first;
 			first = false;
 			if (missing) {
 				process_missing(char_in);
+				la_n = la_i = 0; // the sequence may have changed: look ahead afresh
+				la_off = false;
 			}
 			if (p.debug_stop >= 2 && p.debug_stop < 8) {
 				cover_end = e.len;
@@ -1794,6 +1942,7 @@ struct Machine
 			int64_t target = -1;
 			do {
 				if (roll(h_seq_i, t_seq_i, h_node, t_node, char_out, char_in)) {
+					la_i++;
 					if (char_code(char_in) == CODE_BAD) {
 						target = (int64_t)t_seq_i + (int64_t)p.k;
 					}

@@ -182,10 +182,10 @@ dev_filter(const DevFilter& f)
 {
 	Filter r;
 	r.data = f.data;
-	r.bits = f.nbytes * 8;
+	r.bits = f.counting ? f.nbytes : f.nbytes * 8; // counters vs bits
 	r.mask = (r.bits && (r.bits & (r.bits - 1)) == 0) ? r.bits - 1 : 0;
 	r.hash_num = f.hash_num;
-	r.pad = 0;
+	r.counting = f.counting ? 1 : 0;
 	return r;
 }
 
@@ -196,14 +196,8 @@ refresh_params(ntedit_hip_ctx* c)
 	if (!f.set) {
 		return fail(c, NTEDIT_E_NOFILTER, "primary Bloom filter not set");
 	}
-	if (f.counting) {
-		return fail(c, NTEDIT_E_UNSUPPORTED, "counting Bloom filters are not supported on the HIP path yet");
-	}
 	const DevFilter& r = c->filt[1];
 	if (r.set) {
-		if (r.counting) {
-			return fail(c, NTEDIT_E_UNSUPPORTED, "counting secondary Bloom filter not supported");
-		}
 		if (r.k != f.k) {
 			// ntedit.cpp:2581-2585
 			return fail(
@@ -214,7 +208,7 @@ refresh_params(ntedit_hip_ctx* c)
 			    f.k);
 		}
 	}
-	int rc = nte_host::make_dev_params(c->hp, f.k, f.hash_num, r.set, &c->dp);
+	int rc = nte_host::make_dev_params(c->hp, f.k, f.hash_num, r.set, &c->dp, f.counting);
 	if (rc) {
 		return fail(c, rc, "unsupported parameter combination (k=%u h=%u)", f.k, f.hash_num);
 	}
@@ -350,7 +344,7 @@ bool
 binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_log2, u32* n_slices)
 {
 	const u32 mode = c->hp.screen_mode;
-	if (mode == 1 || f.hash_num == 0 || f.hash_num > 5) {
+	if (mode == 1 || f.hash_num == 0 || f.hash_num > 5 || f.counting) {
 		return false;
 	}
 	u32 slog = 24;
@@ -805,6 +799,9 @@ ntedit_hip_filter_insert(ntedit_hip_ctx* c, int slot, const char* bases, uint64_
 	}
 	HIP_TRY(c, hipSetDevice(c->device));
 	const DevFilter& df = c->filt[slot];
+	if (df.counting) {
+		return fail(c, NTEDIT_E_UNSUPPORTED, "filter_insert: counting filters are built on the host (ntStat)");
+	}
 	// insertion only needs k, the multipliers and the seed tables
 	ntedit_hip_params hp;
 	nte_host::params_default(&hp);

@@ -215,11 +215,11 @@ hash_changelast(HashState& s, const u64* tab, u8 out, u8 in)
 // --------------------------------------------------------------- the filter
 struct Filter
 {
-	const u8* data; // bit array (plain BF), LSB-first within a byte
-	u64 bits;       // array size in bits (= bytes * 8)
+	const u8* data; // plain BF: bit array, LSB-first within a byte; counting BF: 8-bit counters
+	u64 bits;       // number of addressable slots: bits (plain) or counters (counting)
 	u64 mask;       // bits - 1 when bits is a power of two, else 0
 	u32 hash_num;
-	u32 pad;
+	u32 counting;   // 1 = btllib KmerCountingBloomFilter8 (contains() = min counter)
 };
 
 struct DevParams
@@ -236,6 +236,8 @@ struct DevParams
 	u32 start_grid;    // extra event start every start_grid positions inside an absent run
 	u32 node_window;   // live rope nodes kept per event thread
 	u32 debug_stop;    // timing ablations only (NTEDIT_HIP_MACHINE_DEBUG): 1 seed, 2 step 2, 4 first position
+	u32 counting;      // primary filter is a counting filter
+	u32 min_thr, max_thr; // -p / -q (ntedit.cpp:131-132); only meaningful with a counting filter
 	u32 pad0;
 	u64 mul[MAX_HASHES]; // mul[i] = i ^ (k * MULTISEED), i >= 1
 };
@@ -256,11 +258,31 @@ filter_slot(const Filter& f, u64 hv)
 	return f.mask ? (hv & f.mask) : (hv % f.bits);
 }
 
-// contains(): AND of hash_num bits, early exit on the first zero
+// counting filter: contains() returns the smallest of the h counters
+// (btllib CountingBloomFilter::contains; BFWrapper::get_count, ntedit.cpp:373-376)
+NTE_HD u32
+filter_min_count(const Filter& f, const DevParams& p, u64 base)
+{
+	u32 mn = 255;
+	for (unsigned i = 0; i < f.hash_num; i++) {
+		const u32 c = f.data[filter_slot(f, hash_extend(base, p, i))];
+		mn = c < mn ? c : mn;
+		if (mn == 0) {
+			break;
+		}
+	}
+	return mn;
+}
+
+// contains(): AND of hash_num bits, early exit on the first zero (plain);
+// min counter > 0 (counting; BFWrapper::contains, ntedit.cpp:368-371)
 NTE_HD bool
 filter_contains(const Filter& f, const DevParams& p, const HashState& s)
 {
 	u64 base = s.fh + s.rh;
+	if (f.counting) {
+		return filter_min_count(f, p, base) > 0;
+	}
 	for (unsigned i = 0; i < f.hash_num; i++) {
 		u64 n = filter_slot(f, hash_extend(base, p, i));
 		if (!((f.data[n >> 3] >> (n & 7)) & 1)) {
@@ -268,6 +290,18 @@ filter_contains(const Filter& f, const DevParams& p, const HashState& s)
 		}
 	}
 	return true;
+}
+
+// the main loop's test of a k-mer (ntedit.cpp:1806): not contained, or -- counting filter --
+// seen fewer than min_thr (-p) times
+NTE_HD bool
+filter_screen_absent(const Filter& f, const DevParams& p, const HashState& s)
+{
+	if (f.counting) {
+		const u32 c = filter_min_count(f, p, s.fh + s.rh);
+		return c == 0 || c < p.min_thr;
+	}
+	return !filter_contains(f, p, s);
 }
 
 // ------------------------------------------------------- event wire format

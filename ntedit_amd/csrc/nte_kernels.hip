@@ -113,6 +113,7 @@ k_screen(
 	}
 
 	const u32 ksh = (k & 3) * 8;
+	const u32 count_lo = p.min_thr > 1 ? p.min_thr : 1;
 	u64 bits = 0;
 	u32 in_lo = *reinterpret_cast<const u32*>(&s_codes[lds_phys((x0 + k) & ~3u)]);
 	for (u32 j0 = 0; j0 < SCREEN_L; j0 += 4) {
@@ -173,7 +174,7 @@ k_screen(
 					for (int i = 0; i < (H > 0 ? H : 1); i++) {
 						// invalid k-mers read byte 0 instead of branching: keeps all
 						// 4*H gathers independent and in flight together
-						byte[u][i] = f.data[valid[u] ? (slot[u][i] >> 3) : 0];
+						byte[u][i] = f.data[valid[u] ? (f.counting ? slot[u][i] : (slot[u][i] >> 3)) : 0];
 					}
 				}
 #pragma unroll
@@ -181,7 +182,8 @@ k_screen(
 					u32 present = 1;
 #pragma unroll
 					for (int i = 0; i < (H > 0 ? H : 1); i++) {
-						present &= (byte[u][i] >> (slot[u][i] & 7)) & 1;
+						// plain filter: the bit; counting filter: every counter >= max(1, -p)
+						present &= f.counting ? (u32)(byte[u][i] >= count_lo) : ((byte[u][i] >> (slot[u][i] & 7)) & 1);
 					}
 					if (valid[u] && !present) {
 						bits |= 1ULL << (j0 + u);
@@ -191,12 +193,8 @@ k_screen(
 #pragma unroll
 				for (int u = 0; u < 4; u++) {
 					if (valid[u]) {
-						bool present = true;
-						for (u32 i = 0; i < f.hash_num && present; i++) {
-							const u64 s = filter_slot(f, hash_extend(base4[u], p, i));
-							present = (f.data[s >> 3] >> (s & 7)) & 1;
-						}
-						if (!present) {
+						const HashState hb = { base4[u], 0 };
+						if (filter_screen_absent(f, p, hb)) {
 							bits |= 1ULL << (j0 + u);
 						}
 					}

@@ -445,11 +445,33 @@ struct Machine
 		return filter_contains(e.bloom, p, s);
 	}
 
-	// is_kmer_solid (ntedit.cpp:465-473), plain-filter form
+	// BFWrapper::get_count (ntedit.cpp:373-376): min counter, or 1 for a plain filter
+	NTE_HD u32
+	count_of(const HashState& s) const
+	{
+		return e.bloom.counting ? filter_min_count(e.bloom, p, s.fh + s.rh) : 1u;
+	}
+
+	// the main loop's test (ntedit.cpp:1806): not contained, or (counting) seen fewer than -p times
+	NTE_HD bool
+	screen_absent(const HashState& s) const
+	{
+		NTE_COUNT(probes, 1);
+		return filter_screen_absent(e.bloom, p, s);
+	}
+
+	// is_kmer_solid (ntedit.cpp:465-473)
 	NTE_HD bool
 	solid(const HashState& s) const
 	{
-		return !p.secbf || !filter_contains(e.rep, p, s);
+		if (p.secbf && filter_contains(e.rep, p, s)) {
+			return false;
+		}
+		if (e.bloom.counting) {
+			const u32 c = filter_min_count(e.bloom, p, s.fh + s.rh);
+			return c <= p.max_thr && c >= p.min_thr;
+		}
+		return true;
 	}
 
 	NTE_HD bool
@@ -467,8 +489,49 @@ struct Machine
 	NTE_HD u32
 	probe_group(const Filter& f, const u64 (&b)[G], u32 n) const
 	{
-		u32 alive = (1u << n) - 1;
+		return probe_group_range<G>(f, b, n, 1, 255);
+	}
+
+	// counting filters: members are the k-mers whose min counter lies in [lo, hi] (lo >= 1);
+	// plain filters ignore the range
+	template<int G>
+	NTE_HD u32
+	probe_group_range(const Filter& f, const u64 (&b)[G], u32 n, u32 lo, u32 hi, u32 only = 0xFFFFFFFFu) const
+	{
+		u32 alive = ((1u << n) - 1) & only;
 		NTE_COUNT(probes, n);
+		if (f.counting) {
+			u8 mn[G];
+			NTE_UNROLL
+			for (int i = 0; i < G; i++) {
+				mn[i] = 255;
+			}
+			for (u32 h = 0; h < f.hash_num && alive; h++) {
+				u8 byte[G];
+				NTE_UNROLL
+				for (int i = 0; i < G; i++) {
+					byte[i] = 255;
+					if ((alive >> i) & 1) {
+						byte[i] = f.data[filter_slot(f, hash_extend(b[i], p, h))];
+					}
+				}
+				NTE_UNROLL
+				for (int i = 0; i < G; i++) {
+					mn[i] = byte[i] < mn[i] ? byte[i] : mn[i];
+					if (mn[i] == 0) {
+						alive &= ~(1u << i);
+					}
+				}
+			}
+			u32 m = 0;
+			NTE_UNROLL
+			for (int i = 0; i < G; i++) {
+				if (((alive >> i) & 1) && mn[i] >= lo && mn[i] <= hi) {
+					m |= 1u << i;
+				}
+			}
+			return m;
+		}
 		for (u32 h = 0; h < f.hash_num && alive; h++) {
 			u8 byte[G];
 			u8 sh[G];
@@ -497,36 +560,18 @@ struct Machine
 	NTE_HD u32
 	present_group(const u64 (&b)[G], u32 n, bool solid_check) const
 	{
-		u32 m = probe_group<G>(e.bloom, b, n);
+		// contains() alone, or contains() && is_kmer_solid() (counter within [-p, -q] and not
+		// in the secondary filter)
+		u32 lo = 1, hi = 255;
+		if (solid_check && e.bloom.counting) {
+			lo = p.min_thr > 1 ? p.min_thr : 1;
+			hi = p.max_thr;
+		}
+		u32 m = probe_group_range<G>(e.bloom, b, n, lo, hi);
 		if (solid_check && p.secbf && m) {
-			// the secondary filter only matters for k-mers that are present
-			u32 r = 0;
-			for (u32 h = 0; h < e.rep.hash_num; h++) {
-				(void)h;
-			}
-			u32 alive = m;
-			for (u32 h = 0; h < e.rep.hash_num && alive; h++) {
-				u8 byte[G];
-				u8 sh[G];
-				NTE_UNROLL
-				for (int i = 0; i < G; i++) {
-					byte[i] = 0xFF;
-					sh[i] = 0;
-					if ((alive >> i) & 1) {
-						const u64 sl = filter_slot(e.rep, hash_extend(b[i], p, h));
-						byte[i] = e.rep.data[sl >> 3];
-						sh[i] = (u8)(sl & 7);
-					}
-				}
-				NTE_UNROLL
-				for (int i = 0; i < G; i++) {
-					if (!((byte[i] >> sh[i]) & 1)) {
-						alive &= ~(1u << i);
-					}
-				}
-			}
-			r = alive; // in the secondary filter -> not solid
-			m &= ~r;
+			// the secondary filter only matters for k-mers that are present; members of it are not solid
+			const u32 in_rep = probe_group_range<G>(e.rep, b, n, 1, 255, m);
+			m &= ~in_rep;
 		}
 		return m;
 	}
@@ -1603,7 +1648,7 @@ struct Machine
 				for (u32 i = 0; i < lane; i++) {
 					hash_roll(ts, e.tab, win_o(i), win_i(i));
 				}
-				present = in_bloom(ts);
+				present = !screen_absent(ts);
 			}
 			la_mask = (u32)(wave_ballot(present) & 0xFFFFFFFFull);
 			la_n = L;
@@ -1625,7 +1670,7 @@ struct Machine
 					nb = (u32)u + 1;
 				}
 			}
-			la_mask |= probe_group<8>(e.bloom, b, nb) << n;
+			la_mask |= probe_group_range<8>(e.bloom, b, nb, p.min_thr > 1 ? p.min_thr : 1, 255) << n;
 			n += nb;
 		}
 		la_n = L;
@@ -1647,7 +1692,59 @@ struct Machine
 		u32 check_missing = 0;
 		bool do_not_fix = false;
 		win_ok = fill_window();
-		if (win_ok && wc_valid && is_clean()) {
+		if (e.bloom.counting) {
+			// counting filter (ntedit.cpp:1842-1861,1873): besides the missing count, the median
+			// coverage of the k-mers that ARE there decides whether a fix is attempted
+			u32 check_there = 0;
+			for (u32 k = 0; k < p.k && th < e.len; k++) {
+				u8 in;
+				if (win_ok) {
+					in = win_i(k);
+					hash_roll(ts, e.tab, win_o(k), in);
+				} else {
+					if (!roll(th, tt, thn, ttn, char_out, char_in)) {
+						do_not_fix = true;
+						break;
+					}
+					in = char_code(char_in);
+					roll_hash(ts, char_out, char_in);
+				}
+				if (in == CODE_BAD) {
+					do_not_fix = true;
+					break;
+				}
+				if (k % p.jump == 0) {
+					const u32 c = count_of(ts);
+					if (c == 0) {
+						check_missing++;
+					} else if ((draft_char == 'A' || draft_char == 'C' || draft_char == 'G' || draft_char == 'T') &&
+					           c >= p.min_thr) {
+						if (check_there < p.node_window) {
+							e.prev[check_there] = (u8)c;
+						}
+						check_there++;
+					}
+				}
+			}
+			// median of the coverages (ntedit.cpp:455-463): sort, take element n/2; 0 when empty
+			u32 median = 0;
+			const u32 nm = check_there < p.node_window ? check_there : p.node_window;
+			if (nm) {
+				for (u32 i = 1; i < nm; i++) {
+					const u8 v = e.prev[i];
+					u32 j = i;
+					while (j > 0 && e.prev[j - 1] > v) {
+						e.prev[j] = e.prev[j - 1];
+						j--;
+					}
+					e.prev[j] = v;
+				}
+				median = e.prev[nm / 2];
+			}
+			if (do_not_fix || !(check_missing >= p.thr_missing || median < p.min_thr)) {
+				return;
+			}
+		} else if (win_ok && wc_valid && is_clean()) {
 			// Clean state: the k-mers of the confirmation subset are un-edited draft k-mers,
 			// i.e. exactly what the screening pass already answered -- read their bits
 			// (bit = all bases accepted AND absent) instead of probing the filter again.
@@ -1692,7 +1789,7 @@ struct Machine
 				break;
 			}
 		}
-		if (do_not_fix || check_missing < p.thr_missing || p.debug_stop == 2) {
+		if (do_not_fix || (!e.bloom.counting && check_missing < p.thr_missing) || p.debug_stop == 2) {
 			return;
 		}
 
@@ -1915,7 +2012,7 @@ struct Machine
 				if (la_i < la_n) {
 					missing = !((la_mask >> la_i) & 1);
 				} else {
-					missing = !in_bloom(hs);
+					missing = screen_absent(hs);
 				}
 			}
 			const bool was_first = first;

@@ -31,7 +31,7 @@ static const char USAGE[] = PROGRAM
     " Options:\n"
     "	-t,	number of threads (accepted; contigs are polished on the GPU)\n"
     "	-f,	draft genome assembly (FASTA, Multi-FASTA, and/or gzipped compatible), REQUIRED\n"
-    "	-r,	Bloom filter (BF) file (btllib format, e.g. from ntStat v1.0.0+), REQUIRED\n"
+    "	-r,	Bloom filter (BF) or counting BF (CBF) file (btllib format, e.g. from ntStat v1.0.0+), REQUIRED\n"
     "	-e,	secondary BF with k-mers to reject, OPTIONAL\n"
     "	-b,	output file prefix, OPTIONAL\n"
     "	-z,	minimum contig length [default=100]\n"
@@ -48,7 +48,8 @@ static const char USAGE[] = PROGRAM
     "	-l,	input VCF file with annotated variants (accepted, unused on this path)\n"
     "	-a,	soft masks missing k-mer positions having no fix (1 = yes, default = 0, no)\n"
     "	-v,	verbose mode (accepted)\n"
-    "	-p, -q, k-mer coverage thresholds (counting BF only; not available on the HIP path yet)\n"
+    "	-p,	minimum k-mer coverage threshold (CBF only) [default=1]\n"
+    "	-q,	maximum k-mer coverage threshold (CBF only) [default=255]\n"
     "	--gpu N,	HIP device index [default=0]\n"
     "	--batch-bases N,	bases per GPU batch [default=1073741824]\n"
     "	--shard I/N,	polish only every contig whose index mod N == I (multi-GPU sharding)\n"
@@ -293,11 +294,7 @@ main(int argc, char** argv)
 	ntedit_hip_filter_info(ctx, NTEDIT_FILTER_PRIMARY, &k, &h, &nbytes, &counting);
 	printf("BLOOM::\tcounting: %s\tsize: %llu\tnumber hash functions: %u\tkmer size: %u\n", counting ? "YES" : "NO",
 	       (unsigned long long)nbytes, h, k);
-	if (counting) {
-		fprintf(stderr, PROGRAM ": error: counting Bloom filters are not available on the HIP path yet.\n");
-		exit(EXIT_FAILURE);
-	}
-	if (p.min_threshold != 1) {
+	if (!counting && p.min_threshold != 1) {
 		// ntedit.cpp:2453-2458
 		fprintf(stderr, PROGRAM ": warning: Bloom filter is not counting, min k-mer presence threshold will be set to 1.\n");
 		p.min_threshold = 1;
@@ -326,6 +323,9 @@ main(int argc, char** argv)
 	}
 	printf("\n -j %u\n -m %d\n -s %d\n -l %s\n -a %d\n -t %u\n -v %d\n\n", p.jump, p.mode, p.snv, base_name(vcf).c_str(),
 	       p.mask, nthreads, verbose);
+	if (counting) {
+		printf(" -p %u\n -q %u\n\n", p.min_threshold, p.max_threshold); // ntedit.cpp:2519-2522
+	}
 
 	if (!bfrep.empty()) {
 		time(&rawtime);

@@ -90,7 +90,8 @@ make_dev_params(
     uint32_t k,
     uint32_t hash_num,
     bool secbf,
-    nte::DevParams* out)
+    nte::DevParams* out,
+    bool counting)
 {
 	static const uint32_t num_tries[6] = { 0, 1, 5, 21, 85, 341 }; // ntedit.cpp:172
 	if (k < 12 || k > 200 || hash_num == 0 || hash_num > nte::MAX_HASHES || hp.jump == 0 ||
@@ -110,6 +111,10 @@ make_dev_params(
 	d.mode = (uint32_t)hp.mode;
 	d.mask = hp.mask ? 1 : 0;
 	d.secbf = secbf ? 1 : 0;
+	d.counting = counting ? 1 : 0;
+	// ntedit.cpp:2453-2458: -p only exists for counting filters
+	d.min_thr = counting ? hp.min_threshold : 1;
+	d.max_thr = counting ? hp.max_threshold : 255;
 	// ntedit.cpp:2450-2451 (-c is parsed, then overwritten by k*1.5)
 	d.insertion_cap = (uint32_t)((float)k * 1.5f);
 	const float fk = (float)k;

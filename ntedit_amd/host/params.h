@@ -19,6 +19,7 @@ int make_dev_params(
     uint32_t k,
     uint32_t hash_num,
     bool secbf,
-    nte::DevParams* out);
+    nte::DevParams* out,
+    bool counting = false);
 
 } // namespace nte_host

@@ -1976,6 +1976,56 @@ ora_polish_file(
 	return 0;
 }
 
+/* counting-filter variant of the screen: absent <=> min counter is 0 or below min_threshold
+ * (ntedit.cpp:1806-1807) */
+void
+ora_screen_counting_flat(
+    const char* seq,
+    size_t len,
+    const uint8_t* bf_data,
+    uint64_t bf_bytes,
+    unsigned hash_num,
+    unsigned k,
+    unsigned min_threshold,
+    uint64_t* bitmap)
+{
+	ora_bf bf;
+	memset(&bf, 0, sizeof bf);
+	bf.data = (uint8_t*)bf_data;
+	bf.bytes = bf_bytes;
+	bf.bits = bf_bytes * 8;
+	bf.hash_num = hash_num;
+	bf.k = k;
+	bf.counting = 1;
+	size_t nwords = (len + 63) / 64;
+	memset(bitmap, 0, nwords * sizeof(uint64_t));
+	uint64_t hv[64];
+	uint64_t fh = 0, rh = 0;
+	size_t run = 0;
+	for (size_t i = 0; i < len; i++) {
+		if (!isAcceptedBase((unsigned char)toupper((unsigned char)seq[i]))) {
+			run = 0;
+			continue;
+		}
+		run++;
+		if (run == k) {
+			fh = ora_base_forward_hash(seq + i + 1 - k, k);
+			rh = ora_base_reverse_hash(seq + i + 1 - k, k);
+		} else if (run > k) {
+			fh = ora_next_forward_hash(fh, k, (unsigned char)seq[i - k], (unsigned char)seq[i]);
+			rh = ora_next_reverse_hash(rh, k, (unsigned char)seq[i - k], (unsigned char)seq[i]);
+		} else {
+			continue;
+		}
+		ora_extend_hashes(fh + rh, k, hash_num, hv);
+		unsigned c = ora_bf_contains(&bf, hv);
+		if (c == 0 || c < min_threshold) {
+			size_t s = i + 1 - k;
+			bitmap[s >> 6] |= 1ULL << (s & 63);
+		}
+	}
+}
+
 /* flat-argument wrapper for ctypes callers (tests) */
 void
 ora_screen_flat(

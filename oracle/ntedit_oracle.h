@@ -122,6 +122,16 @@ void ora_screen_flat(
     unsigned k,
     uint64_t* bitmap);
 
+void ora_screen_counting_flat(
+    const char* seq,
+    size_t len,
+    const uint8_t* bf_data,
+    uint64_t bf_bytes,
+    unsigned hash_num,
+    unsigned k,
+    unsigned min_threshold,
+    uint64_t* bitmap);
+
 uint64_t ora_polish_batch_flat(
     const char* bases,
     const uint64_t* offsets,

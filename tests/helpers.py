@@ -182,13 +182,15 @@ def run_hostsim(recs, bf, params, out_prefix, rep=None):
         ctypes.c_uint32(rep["hash_num"] if rep else 0),
         ctypes.byref(params),
         (out_prefix + "_edited.fa").encode(), (out_prefix + "_changes.tsv").encode(),
-        ctypes.byref(nev), ctypes.byref(nap))
+        ctypes.byref(nev), ctypes.byref(nap),
+        ctypes.c_int(1 if bf.get("counting") else 0), ctypes.c_int(1 if (rep and rep.get("counting")) else 0))
     return rc, nev.value, nap.value
 
 
 def oracle_args(params):
     a = ["-z", str(params.min_contig_len), "-i", str(params.max_insertions), "-d", str(params.max_deletions),
-         "-j", str(params.jump), "-m", str(params.mode), "-a", str(params.mask)]
+         "-j", str(params.jump), "-m", str(params.mode), "-a", str(params.mask),
+         "-p", str(params.min_threshold), "-q", str(params.max_threshold)]
     if params.use_ratio:
         a += ["-X", repr(float(params.missing_ratio)), "-Y", repr(float(params.edit_ratio))]
     else:
@@ -205,10 +207,10 @@ def run_oracle(draft_path, bf_path, params, out_prefix, rep_path=None):
     subprocess.run(cmd, check=True)
 
 
-def mkbf(fasta_paths, out, k=25, hashes=3, nbytes=1 << 20):
+def mkbf(fasta_paths, out, k=25, hashes=3, nbytes=1 << 20, counting=False):
     build_oracle()
     subprocess.run([os.path.join(ORACLE_BUILD, "mkbf"), "-k", str(k), "-g", str(hashes), "-s", str(nbytes),
-                    "-o", out] + list(fasta_paths), check=True)
+                    "-o", out] + (["-C"] if counting else []) + list(fasta_paths), check=True)
 
 
 # ---------------------------------------------------------------- synthetic data
@@ -242,9 +244,15 @@ def mutate(rng, seq, p_sub=1e-3, p_ins=1e-4, p_del=1e-4, max_indel=5):
     return bytes(out)
 
 
-def oracle_screen(blob, bf):
+def oracle_screen(blob, bf, min_threshold=1):
     lib = oracle_lib()
     out = np.zeros((len(blob) + 63) // 64, dtype=np.uint64)
+    if bf.get("counting"):
+        lib.ora_screen_counting_flat(ctypes.c_char_p(blob), ctypes.c_size_t(len(blob)),
+                                     bf["data"].ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bf["bytes"]),
+                                     ctypes.c_uint(bf["hash_num"]), ctypes.c_uint(bf["k"]),
+                                     ctypes.c_uint(min_threshold), out.ctypes.data_as(ctypes.c_void_p))
+        return out
     lib.ora_screen_flat(ctypes.c_char_p(blob), ctypes.c_size_t(len(blob)),
                         bf["data"].ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bf["bytes"]),
                         ctypes.c_uint(bf["hash_num"]), ctypes.c_uint(bf["k"]),
@@ -267,7 +275,18 @@ def make_case(tmp, seed, n=60000, p_sub=2e-3, p_ins=3e-4, p_del=3e-4, k=25, hash
         t[pos:pos + len(rep)] = rep
         truth[0] = bytes(t)
     write_fasta(os.path.join(tmp, "truth.fa"), [(b"t%d" % i, s) for i, s in enumerate(truth)])
-    mkbf([os.path.join(tmp, "truth.fa")], os.path.join(tmp, "t.bf"), k=k, hashes=hashes, nbytes=bfbytes)
+    if "cbf" in flavor:
+        # counting filter: the genome 3x, its first third two more times, one stretch only once
+        write_fasta(os.path.join(tmp, "part.fa"), [(b"p%d" % i, s[: len(s) // 3]) for i, s in enumerate(truth)])
+        lo = [(b"l%d" % i, s[len(s) // 2: len(s) // 2 + 3000]) for i, s in enumerate(truth)]
+        thin = [(b"t%d" % i, s[: len(s) // 2] ) for i, s in enumerate(truth)] + \
+               [(b"u%d" % i, s[len(s) // 2 + 3000:]) for i, s in enumerate(truth)]
+        write_fasta(os.path.join(tmp, "thin.fa"), thin)
+        write_fasta(os.path.join(tmp, "lo.fa"), lo)
+        srcs = [os.path.join(tmp, "thin.fa")] * 3 + [os.path.join(tmp, "part.fa")] * 2 + [os.path.join(tmp, "lo.fa")]
+        mkbf(srcs, os.path.join(tmp, "t.bf"), k=k, hashes=hashes, nbytes=bfbytes * 8, counting=True)
+    else:
+        mkbf([os.path.join(tmp, "truth.fa")], os.path.join(tmp, "t.bf"), k=k, hashes=hashes, nbytes=bfbytes)
     draft = []
     for i, s in enumerate(truth):
         d = bytearray(mutate(rng, s, p_sub, p_ins, p_del))
@@ -322,4 +341,10 @@ PARITY_CONFIGS = [
     (dict(hashes=4, bfbytes=100003 * 8), dict()),
     (dict(hashes=1, bfbytes=1 << 18), dict()),
     (dict(hashes=6, bfbytes=(1 << 18) + 8), dict()),
+    # counting Bloom filters (KmerCountingBloomFilter8): -p / -q thresholds, coverage medians
+    (dict(flavor="cbf"), dict()),
+    (dict(flavor="cbf"), dict(min_threshold=2)),
+    (dict(flavor="cbf N iupac"), dict(min_threshold=3, max_threshold=4)),
+    (dict(flavor="cbf", hashes=2, bfbytes=50021), dict(min_threshold=2, mode=1)),
+    (dict(flavor="cbf sec"), dict(min_threshold=2, max_threshold=5, mode=2, max_insertions=2, max_deletions=2)),
 ]

@@ -21,14 +21,14 @@ namespace nte { WorkCounters g_wc; }
 using namespace nte;
 
 static Filter
-make_filter(const uint8_t* data, uint64_t nbytes, uint32_t hash_num)
+make_filter(const uint8_t* data, uint64_t nbytes, uint32_t hash_num, bool counting = false)
 {
 	Filter f;
 	f.data = data;
-	f.bits = nbytes * 8;
-	f.mask = (f.bits & (f.bits - 1)) == 0 ? f.bits - 1 : 0;
+	f.bits = counting ? nbytes : nbytes * 8;
+	f.mask = (f.bits && (f.bits & (f.bits - 1)) == 0) ? f.bits - 1 : 0;
 	f.hash_num = hash_num;
-	f.pad = 0;
+	f.counting = counting ? 1 : 0;
 	return f;
 }
 
@@ -45,7 +45,7 @@ sim_screen(const u8* seq, u64 n, const Filter& f, const DevParams& p, const u64*
 		hash_roll(hs, tab, out, in);
 		good = in == CODE_BAD ? 0 : good + 1;
 		if (good >= p.k) {
-			if (!filter_contains(f, p, hs)) {
+			if (filter_screen_absent(f, p, hs)) {
 				u64 s = i + 1 - p.k;
 				bitmap[s >> 6] |= 1ULL << (s & 63);
 			}
@@ -61,17 +61,20 @@ hostsim_screen(
     uint64_t bf_bytes,
     uint32_t hash_num,
     uint32_t k,
-    uint64_t* bitmap)
+    uint64_t* bitmap,
+    int counting,
+    uint32_t min_threshold)
 {
 	ntedit_hip_params hp;
 	nte_host::params_default(&hp);
+	hp.min_threshold = min_threshold;
 	DevParams p;
-	if (nte_host::make_dev_params(hp, k, hash_num, false, &p)) {
+	if (nte_host::make_dev_params(hp, k, hash_num, false, &p, counting != 0)) {
 		return -1;
 	}
 	u64 tab[TAB_WORDS];
 	build_seed_tables(k, tab);
-	Filter f = make_filter(bf, bf_bytes, hash_num);
+	Filter f = make_filter(bf, bf_bytes, hash_num, counting != 0);
 	sim_screen((const u8*)bases, n, f, p, tab, bitmap);
 	return 0;
 }
@@ -95,17 +98,19 @@ hostsim_polish(
     const char* fa_path,
     const char* tsv_path,
     uint64_t* n_events_out,
-    uint64_t* n_applied_out)
+    uint64_t* n_applied_out,
+    int counting,
+    int rep_counting)
 {
 	DevParams p;
-	int rc = nte_host::make_dev_params(*hp, k, hash_num, rep != nullptr, &p);
+	int rc = nte_host::make_dev_params(*hp, k, hash_num, rep != nullptr, &p, counting != 0);
 	if (rc) {
 		return rc;
 	}
 	u64 tab[TAB_WORDS];
 	build_seed_tables(k, tab);
-	Filter f = make_filter(bf, bf_bytes, hash_num);
-	Filter fr = make_filter(rep, rep_bytes, rep ? rep_hash_num : 0);
+	Filter f = make_filter(bf, bf_bytes, hash_num, counting != 0);
+	Filter fr = make_filter(rep, rep_bytes, rep ? rep_hash_num : 0, rep_counting != 0);
 
 	std::vector<u64> bitmap((n + 63) / 64 + 1);
 	sim_screen((const u8*)bases, n, f, p, tab, bitmap.data());
@@ -202,7 +207,7 @@ hostsim_polish(
 	FILE* fa = fa_path ? fopen(fa_path, "w") : nullptr;
 	FILE* tsv = tsv_path ? fopen(tsv_path, "w") : nullptr;
 	if (tsv) {
-		nte_host::write_tsv_header(tsv, k, hp->jump, false);
+		nte_host::write_tsv_header(tsv, k, hp->jump, counting != 0);
 	}
 	nte_host::RenderStats st;
 	rc = nte_host::render_batch(

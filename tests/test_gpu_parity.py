@@ -55,15 +55,16 @@ def test_polish_matches_oracle(tmp_path, ci, oracle_build):
     assert st.events >= st.events_applied
 
 
-@pytest.mark.parametrize("ci", [0, 1, 3, 16, 23, 24, 25])
+@pytest.mark.parametrize("ci", [0, 1, 3, 16, 23, 24, 25, 26, 27, 28, 29])
 def test_screen_bitmap_matches_oracle(tmp_path, ci, polisher, oracle_build):
-    case_kw, _ = H.PARITY_CONFIGS[ci]
+    case_kw, par_kw = H.PARITY_CONFIGS[ci]
     case = H.make_case(str(tmp_path), 2000 + ci, **case_kw)
     bf = H.load_bf(case["bf"])
     blob, offs, lens, names = H.pack_batch(H.read_fasta(case["draft"]))
-    polisher.set_filter(bf["data"], bf["hash_num"], bf["k"])
+    polisher.set_filter(bf["data"], bf["hash_num"], bf["k"], counting=bf["counting"])
+    polisher.set_params(_hip_params(**par_kw))
     got = polisher.screen(blob)
-    want = H.oracle_screen(blob, bf)
+    want = H.oracle_screen(blob, bf, par_kw.get("min_threshold", 1))
     assert got.shape == want.shape
     assert np.array_equal(got, want)
     assert int(np.unpackbits(got.view(np.uint8)).sum()) > 0

@@ -122,6 +122,6 @@ def test_host_device_header_matches_oracle_screen(tmp_path, oracle_build):
         got = np.zeros_like(want)
         rc = sim.hostsim_screen(ctypes.c_char_p(blob), ctypes.c_uint64(len(blob)),
                                 bf["data"].ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bf["bytes"]),
-                                ctypes.c_uint32(h), ctypes.c_uint32(k), got.ctypes.data_as(ctypes.c_void_p))
+                                ctypes.c_uint32(h), ctypes.c_uint32(k), got.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(0), ctypes.c_uint32(1))
         assert rc == 0
         assert np.array_equal(got, want)

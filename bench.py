@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--screen-only", action="store_true", help="time only the screening kernel (profiling aid)")
     ap.add_argument("--start-grid", type=int, default=0, help="event start grid override (tuning)")
     ap.add_argument("--screen-mode", type=int, default=0, help="0 auto, 1 direct gather, 2 L2-partitioned")
+    ap.add_argument("--shared-filter", action="store_true",
+                    help="use the multi-GPU filter path (torch-owned filter tensor + broadcast) even with 1 rank")
     return ap.parse_args()
 
 
@@ -125,10 +127,16 @@ def main():
     pol.set_params(ntedit_amd.default_params(start_grid=args.start_grid, screen_mode=args.screen_mode))
     t_setup = time.perf_counter()
     # same truth genome on every rank; rank 0 builds the filter and broadcasts it (RCCL)
+    shared = world > 1 or args.shared_filter
+    if shared:
+        fbuf = ndist.shared_filter(pol, args.filter_bytes, args.hashes, args.k)
+        build = "insert" if rank == 0 else False
+    else:
+        build = "alloc"
     job = SyntheticJob(pol, args.bases, k=args.k, hash_num=args.hashes, filter_bytes=args.filter_bytes,
-                       seed=20251031, draft_seed=20251032 + rank, device=dev, build_filter=(rank == 0 or world == 1))
-    if world > 1:
-        ndist.broadcast_filter(pol, src=0)
+                       seed=20251031, draft_seed=20251032 + rank, device=dev, build_filter=build)
+    if shared:
+        ndist.broadcast_filter(fbuf, src=0)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 

@@ -55,34 +55,67 @@ def broadcast_filter_tensor(t, src=0):
     return t
 
 
-def broadcast_filter(polisher, meta=None, src=0):
-    """Rank `src` holds the filter in its Polisher; afterwards every rank's Polisher
-    points at an identical HBM copy.  meta = (k, hash_num, nbytes) must be known on
-    every rank (it is broadcast as a tiny tensor first)."""
+def shared_filter(polisher, nbytes, hash_num, k, slot=0):
+    """Allocate the filter bit array as a torch tensor on this rank's GPU and let the library
+    adopt it (ntedit_hip_set_filter_device).  Every rank calls this with the same geometry;
+    rank `src` then fills it (filter_insert / copy_) and broadcast_filter() ships it."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nbytes = (int(nbytes) + 7) // 8 * 8
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    polisher.set_filter_device(buf.data_ptr(), nbytes, hash_num, k, slot=slot)
+    if not hasattr(polisher, "_filter_keepalive"):
+        polisher._filter_keepalive = {}
+    polisher._filter_keepalive[slot] = buf
+    return buf
+
+
+def broadcast_filter(buf, src=0):
+    """The path's single data-path collective: one broadcast of the filter bit array
+    (RCCL over xGMI).  `buf` is the tensor returned by shared_filter()."""
+    import torch
+    torch.cuda.synchronize()
+    broadcast_filter_tensor(buf, src)
+    torch.cuda.synchronize()
+    return buf
+
+
+def load_and_broadcast_filter(polisher, path, src=0, slot=0):
+    """Rank `src` reads a btllib .bf file; every rank ends up with the same filter in HBM."""
     import torch
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
     dev = torch.device("cuda", torch.cuda.current_device())
-    hdr = torch.zeros(3, dtype=torch.int64, device=dev)
+    hdr = torch.zeros(4, dtype=torch.int64, device=dev)
+    data = None
     if rank == src:
-        k, h, nbytes, _ = polisher.filter_info(0)
-        hdr[0], hdr[1], hdr[2] = k, h, nbytes
+        meta = {}
+        with open(path, "rb") as f:
+            first = f.readline()
+            counting = b"Counting" in first
+            while True:
+                line = f.readline()
+                if not line or line.startswith(b"[HeaderEnd]"):
+                    break
+                if b"=" in line:
+                    key, val = [x.strip() for x in line.split(b"=", 1)]
+                    meta[key.decode()] = val.decode().strip('"')
+            off = f.tell()
+        nbytes = int(meta["bytes"])
+        data = np.memmap(path, dtype=np.uint8, mode="r", offset=off, shape=(nbytes,))
+        hdr[0], hdr[1], hdr[2], hdr[3] = int(meta["k"]), int(meta["hash_num"]), nbytes, int(counting)
     broadcast_filter_tensor(hdr, src)
-    k, h, nbytes = int(hdr[0]), int(hdr[1]), int(hdr[2])
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    k, h, nbytes, counting = [int(x) for x in hdr.tolist()]
+    pad = (nbytes + 7) // 8 * 8
+    buf = torch.zeros(pad, dtype=torch.uint8, device=dev)
     if rank == src:
-        # device-to-device copy of rank src's filter into the collective buffer
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-        rc = hip.hipMemcpy(buf.data_ptr(), polisher.filter_device_ptr(0), nbytes, 3)
-        if rc:
-            raise RuntimeError("hipMemcpy D2D failed (%d)" % rc)
-    torch.cuda.synchronize()
-    broadcast_filter_tensor(buf, src)
-    torch.cuda.synchronize()
-    polisher.set_filter_device(buf.data_ptr(), nbytes, h, k)
-    polisher._filter_keepalive = buf
+        buf[:nbytes].copy_(torch.from_numpy(np.ascontiguousarray(data)))
+    broadcast_filter(buf, src)
+    polisher.set_filter_device(buf.data_ptr(), pad, h, k, slot=slot, counting=bool(counting))
+    if not hasattr(polisher, "_filter_keepalive"):
+        polisher._filter_keepalive = {}
+    polisher._filter_keepalive[slot] = buf
     return buf
 
 

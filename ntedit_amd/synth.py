@@ -85,7 +85,9 @@ class SyntheticJob:
     mutated draft, laid out as one batch (contigs separated by '\\n') in HBM."""
 
     def __init__(self, polisher, total_bases, k=25, hash_num=3, filter_bytes=1 << 32, seed=20251031,
-                 draft_seed=None, device="cuda", build_filter=True, n_runs=True):
+                 draft_seed=None, device="cuda", build_filter="alloc", n_runs=True):
+        """build_filter: "alloc" = allocate a filter in the library and fill it; "insert" = fill the
+        filter the polisher already has (e.g. a shared tensor); False = leave the filter alone."""
         self.total_bases = int(total_bases)
         dev = torch.device(device)
         lens = contig_lengths(total_bases, seed)
@@ -93,7 +95,7 @@ class SyntheticJob:
         gen_t.manual_seed(seed)
         gen_d = torch.Generator(device=dev)
         gen_d.manual_seed((seed + 1) if draft_seed is None else draft_seed)
-        if build_filter:
+        if build_filter == "alloc":
             polisher.filter_alloc(filter_bytes, hash_num, k)
         parts, offs, dlens = [], [], []
         pos = 0

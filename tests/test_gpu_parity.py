@@ -200,3 +200,23 @@ def test_polish_chunk_pipeline(tmp_path, ci, oracle_build, monkeypatch):
     for g in ("g", "g2"):
         assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / (g + "_changes.tsv")), shallow=False)
         assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / (g + "_edited.fa")), shallow=False)
+
+
+def test_golden_cases_on_gpu(tmp_path):
+    """committed golden vectors (tests/golden/cases) through the C ABI"""
+    import test_golden as TG
+    for name in TG.CASES:
+        d = os.path.join(H.GOLDEN, "cases", name)
+        hp = TG.params_from_file(os.path.join(d, "params.txt"))
+        pol = _fresh()
+        try:
+            pol.load_filter_file(os.path.join(d, "filter.bf"), 0)
+            if os.path.exists(os.path.join(d, "secondary.bf")):
+                pol.load_filter_file(os.path.join(d, "secondary.bf"), 1)
+            kw = {f[0]: getattr(hp, f[0]) for f in hp._fields_}
+            pol.set_params(_hip_params(**kw))
+            pol.polish_records(H.read_fasta(os.path.join(d, "draft.fa")), str(tmp_path / name))
+        finally:
+            pol.close()
+        assert filecmp.cmp(os.path.join(d, "expected_changes.tsv"), str(tmp_path / (name + "_changes.tsv")), shallow=False), name
+        assert filecmp.cmp(os.path.join(d, "expected_edited.fa"), str(tmp_path / (name + "_edited.fa")), shallow=False), name

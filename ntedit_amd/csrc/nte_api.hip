@@ -344,7 +344,7 @@ bool
 binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_log2, u32* n_slices)
 {
 	const u32 mode = c->hp.screen_mode;
-	if (mode == 1 || f.hash_num == 0 || f.hash_num > 5 || f.counting) {
+	if (mode == 1 || f.hash_num == 0 || f.hash_num > 5 || f.counting || c->hp.snv) {
 		return false;
 	}
 	u32 slog = 24;

@@ -129,6 +129,68 @@ seed_rev_of_code(u8 code)
 	}
 }
 
+// Seeds by raw byte, exactly SEED_TAB[c] / SEED_TAB[c & 7]: also defined for characters that
+// are not accepted bases.  U/u hash like T, and a handful of other bytes pick up a
+// complement-slot seed on the reverse strand through (c & 7).  The 4-bit codes above fold all
+// of those into CODE_BAD (seed 0), which is exact for N/n and for separators; the raw forms
+// are used wherever a k-mer that contains such a byte can actually be hashed.
+NTE_HD u64
+seed_fwd_raw(u8 c)
+{
+	switch (c) {
+	case 'A':
+	case 'a':
+		return SEED_A;
+	case 'C':
+	case 'c':
+		return SEED_C;
+	case 'G':
+	case 'g':
+		return SEED_G;
+	case 'T':
+	case 't':
+	case 'U':
+	case 'u':
+		return SEED_T;
+	case 1:
+		return SEED_T;
+	case 3:
+		return SEED_G;
+	case 4:
+	case 5:
+		return SEED_A;
+	case 7:
+		return SEED_C;
+	default:
+		return 0;
+	}
+}
+
+NTE_HD u64
+seed_rev_raw(u8 c)
+{
+	switch (c & 7) {
+	case 1:
+		return SEED_T;
+	case 3:
+		return SEED_G;
+	case 4:
+	case 5:
+		return SEED_A;
+	case 7:
+		return SEED_C;
+	default:
+		return 0;
+	}
+}
+
+// a byte whose 4-bit code (CODE_BAD -> zero seeds) would NOT reproduce its raw seeds
+NTE_HD bool
+is_exotic(u8 c)
+{
+	return char_code(c) == CODE_BAD && (seed_fwd_raw(c) != 0 || seed_rev_raw(c) != 0);
+}
+
 // ---------------------------------------------------------------- rotations
 // ntHash2 "split rotate": bits 0..32 and bits 33..63 rotate independently.
 NTE_HD u64
@@ -212,6 +274,21 @@ hash_changelast(HashState& s, const u64* tab, u8 out, u8 in)
 	s.rh ^= tab[TAB_RK1 + out] ^ tab[TAB_RK1 + in];
 }
 
+// raw-byte forms of the two updates (same arithmetic, seeds from the bytes themselves)
+NTE_HD void
+hash_roll_raw(HashState& s, unsigned k, u8 out, u8 in)
+{
+	s.fh = srol1(s.fh) ^ seed_fwd_raw(in) ^ sroln(seed_fwd_raw(out), k);
+	s.rh = sror1(s.rh ^ sroln(seed_rev_raw(in), k) ^ seed_rev_raw(out));
+}
+
+NTE_HD void
+hash_changelast_raw(HashState& s, unsigned k, u8 out, u8 in)
+{
+	s.fh ^= seed_fwd_raw(out) ^ seed_fwd_raw(in);
+	s.rh ^= sroln(seed_rev_raw(out), k - 1) ^ sroln(seed_rev_raw(in), k - 1);
+}
+
 // --------------------------------------------------------------- the filter
 struct Filter
 {
@@ -237,8 +314,8 @@ struct DevParams
 	u32 node_window;   // live rope nodes kept per event thread
 	u32 debug_stop;    // timing ablations only (NTEDIT_HIP_MACHINE_DEBUG): 1 seed, 2 step 2, 4 first position
 	u32 counting;      // primary filter is a counting filter
+	u32 snv;           // -s 1: every position is re-assessed (ntedit.cpp:1806,1865)
 	u32 min_thr, max_thr; // -p / -q (ntedit.cpp:131-132); only meaningful with a counting filter
-	u32 pad0;
 	u64 mul[MAX_HASHES]; // mul[i] = i ^ (k * MULTISEED), i >= 1
 };
 

@@ -165,6 +165,14 @@ k_screen(
 					}
 				}
 			}
+		} else if (p.snv) {
+			// -s 1: every k-mer of accepted bases is re-assessed, no probe decides that
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				if (valid[u]) {
+					bits |= 1ULL << (j0 + u);
+				}
+			}
 		} else {
 			if (H > 0) {
 				u8 byte[4][H > 0 ? H : 1];

@@ -659,13 +659,23 @@ struct Machine
 	roll_hash(HashState& s, u8 char_out, u8 char_in) const
 	{
 		NTE_COUNT(slow_rolls, 1);
-		hash_roll(s, e.tab, char_code(char_out), char_code(char_in));
+		const u8 co = char_code(char_out), ci = char_code(char_in);
+		if ((co == CODE_BAD && is_exotic(char_out)) || (ci == CODE_BAD && is_exotic(char_in))) {
+			hash_roll_raw(s, p.k, char_out, char_in); // rare: U, '-', '*', ... inside a hashed k-mer
+		} else {
+			hash_roll(s, e.tab, co, ci);
+		}
 	}
 
 	NTE_HD void
 	changelast(HashState& s, u8 char_out, u8 char_in) const
 	{
-		hash_changelast(s, e.tab, char_code(char_out), char_code(char_in));
+		const u8 co = char_code(char_out), ci = char_code(char_in);
+		if ((co == CODE_BAD && is_exotic(char_out)) || (ci == CODE_BAD && is_exotic(char_in))) {
+			hash_changelast_raw(s, p.k, char_out, char_in);
+		} else {
+			hash_changelast(s, e.tab, co, ci);
+		}
 	}
 
 	// ------------------------------------------------ rope edit primitives
@@ -1036,6 +1046,7 @@ struct Machine
 			const u64 a0 = g0 & ~7ULL;
 			u32 filled = 0;
 			u32 skip = (u32)(g0 - a0);
+			bool exotic = false;
 			for (u64 a = a0; filled < want; a += 8) {
 				u64 w = 0;
 				if (base + a + 8 <= e.batch_end) {
@@ -1047,11 +1058,20 @@ struct Machine
 				}
 				w >>= 8 * skip;
 				for (u32 b = skip; b < 8 && filled < want; b++) {
-					e.win[(u64)filled * e.win_stride] = char_code((u8)(w & 0xFF));
+					const u8 ch = (u8)(w & 0xFF);
+					const u8 code = char_code(ch);
+					exotic |= code == CODE_BAD && is_exotic(ch);
+					e.win[(u64)filled * e.win_stride] = code;
 					w >>= 8;
 					filled++;
 				}
 				skip = 0;
+			}
+			if (exotic) {
+				// a byte whose hash seeds the 4-bit codes cannot express (U, '-', ...): let the
+				// reference-shaped code paths hash it from the raw bytes
+				wc_valid = false;
+				return false;
 			}
 			wc_valid = true;
 			wc_pos0 = h_seq_i;
@@ -1126,7 +1146,12 @@ struct Machine
 					}
 					w >>= 8 * skip;
 					for (u32 b = skip; b < 8 && filled < take; b++) {
-						e.win[(u64)(dst + done + filled) * e.win_stride] = char_code((u8)(w & 0xFF));
+						const u8 ch = (u8)(w & 0xFF);
+						const u8 code = char_code(ch);
+						if (code == CODE_BAD && is_exotic(ch)) {
+							return false; // see fill_window
+						}
+						e.win[(u64)(dst + done + filled) * e.win_stride] = code;
 						w >>= 8;
 						filled++;
 					}
@@ -1531,9 +1556,10 @@ struct Machine
 		}
 	}
 
-	// substitution candidates for a draft base (ntedit.cpp:180-186, polish mode)
+	// substitution candidates for a draft base: polish_bases_array / snv_bases_array
+	// (ntedit.cpp:180-199)
 	NTE_HD static u32
-	candidate_bases(u8 draft_char, u8* out)
+	candidate_bases(u8 draft_char, bool snv, u8* out)
 	{
 		const char* s;
 		switch (draft_char) {
@@ -1550,34 +1576,34 @@ struct Machine
 			s = "ATC";
 			break;
 		case 'R':
-			s = "TC";
+			s = snv ? "ATCG" : "TC";
 			break;
 		case 'Y':
-			s = "AG";
+			s = snv ? "ATCG" : "AG";
 			break;
 		case 'S':
-			s = "AT";
+			s = snv ? "ATCG" : "AT";
 			break;
 		case 'W':
-			s = "CG";
+			s = snv ? "ATCG" : "CG";
 			break;
 		case 'K':
-			s = "AC";
+			s = snv ? "ATCG" : "AC";
 			break;
 		case 'M':
-			s = "TG";
+			s = snv ? "ATCG" : "TG";
 			break;
 		case 'B':
-			s = "A";
+			s = snv ? "ATCG" : "A";
 			break;
 		case 'D':
-			s = "C";
+			s = snv ? "ATCG" : "C";
 			break;
 		case 'H':
-			s = "G";
+			s = snv ? "ATCG" : "G";
 			break;
 		case 'V':
-			s = "T";
+			s = snv ? "ATCG" : "T";
 			break;
 		case 'N':
 			s = "ATCG";
@@ -1692,10 +1718,12 @@ struct Machine
 		u32 check_missing = 0;
 		bool do_not_fix = false;
 		win_ok = fill_window();
-		if (e.bloom.counting) {
-			// counting filter (ntedit.cpp:1842-1861,1873): besides the missing count, the median
-			// coverage of the k-mers that ARE there decides whether a fix is attempted
-			u32 check_there = 0;
+		u32 check_there = 0, there_median = 0;
+		if (e.bloom.counting || p.snv) {
+			// counting filter / SNV mode (ntedit.cpp:1842-1861,1873,1890-1914): besides the
+			// missing count, the k-mers that ARE there matter -- their median coverage decides
+			// whether a fix is attempted, and in SNV mode their number is the draft base's own
+			// support that a substitution has to match
 			for (u32 k = 0; k < p.k && th < e.len; k++) {
 				u8 in;
 				if (win_ok) {
@@ -1714,7 +1742,7 @@ struct Machine
 					break;
 				}
 				if (k % p.jump == 0) {
-					const u32 c = count_of(ts);
+					const u32 c = e.bloom.counting ? count_of(ts) : (in_bloom(ts) ? 1u : 0u);
 					if (c == 0) {
 						check_missing++;
 					} else if ((draft_char == 'A' || draft_char == 'C' || draft_char == 'G' || draft_char == 'T') &&
@@ -1741,7 +1769,9 @@ struct Machine
 				}
 				median = e.prev[nm / 2];
 			}
-			if (do_not_fix || !(check_missing >= p.thr_missing || median < p.min_thr)) {
+			there_median = median;
+			if (!p.snv &&
+			    (do_not_fix || !(check_missing >= p.thr_missing || (e.bloom.counting && median < p.min_thr)))) {
 				return;
 			}
 		} else if (win_ok && wc_valid && is_clean()) {
@@ -1789,7 +1819,7 @@ struct Machine
 				break;
 			}
 		}
-		if (do_not_fix || (!e.bloom.counting && check_missing < p.thr_missing) || p.debug_stop == 2) {
+		if ((!p.snv && (do_not_fix || (!e.bloom.counting && check_missing < p.thr_missing))) || p.debug_stop == 2) {
 			return;
 		}
 
@@ -1801,9 +1831,14 @@ struct Machine
 		b.num_support = 0;
 		b.altbase1 = b.altbase2 = b.altbase3 = 0;
 		b.altsupp1 = b.altsupp2 = b.altsupp3 = 0;
+		if (p.snv && check_there >= p.thr_edit) {
+			// the draft base's own support is the bar (ntedit.cpp:1890-1903)
+			b.sub_base = draft_char;
+			b.num_support = e.bloom.counting ? there_median : check_there;
+		}
 
 		u8 cand[4];
-		u32 n_cand = candidate_bases(draft_char, cand);
+		u32 n_cand = candidate_bases(draft_char, p.snv != 0, cand);
 		Node t_nd = nget(t_node);
 		for (u32 ci = 0; ci < n_cand; ci++) {
 			u8 sub_base = cand[ci];
@@ -2006,13 +2041,17 @@ struct Machine
 				}
 				missing = true; // clean state: the screening bitmap already answered
 			} else {
-				if (la_i >= la_n && !la_off) {
-					build_lookahead();
-				}
-				if (la_i < la_n) {
-					missing = !((la_mask >> la_i) & 1);
+				if (p.snv) {
+					missing = true;
 				} else {
-					missing = screen_absent(hs);
+					if (la_i >= la_n && !la_off) {
+						build_lookahead();
+					}
+					if (la_i < la_n) {
+						missing = !((la_mask >> la_i) & 1);
+					} else {
+						missing = screen_absent(hs);
+					}
 				}
 			}
 			const bool was_first = first;

@@ -44,7 +44,7 @@ static const char USAGE[] = PROGRAM
     "	-c,	cap for the number of base insertions at one position (parsed; k*1.5 is used)\n"
     "	-j, 	controls size of k-mer subset, check every jth k-mer, [default=3]\n"
     "	-m,	mode of editing, range 0-2, [default=0]\n"
-    "	-s,     SNV mode (not available on the HIP path yet)\n"
+    "	-s,     SNV mode. Overrides draft k-mer checks, forcing reassessment at each position (-s 1 = yes, default = 0, no)\n"
     "	-l,	input VCF file with annotated variants (accepted, unused on this path)\n"
     "	-a,	soft masks missing k-mer positions having no fix (1 = yes, default = 0, no)\n"
     "	-v,	verbose mode (accepted)\n"
@@ -273,8 +273,9 @@ main(int argc, char** argv)
 		exit(EXIT_FAILURE);
 	}
 	if (p.snv) {
-		fprintf(stderr, PROGRAM ": error: SNV mode (-s 1) is not available on the HIP path yet.\n");
-		exit(EXIT_FAILURE);
+		// ntedit.cpp:2411-2417
+		fprintf(stderr, "\nSNV mode ON\nTracking all single-base variants\nNote: -i and -d both set to 0 when -s is set to 1\n"
+		                "(this build writes _edited.fa and _changes.tsv; the VCF body is not produced)\n\n");
 	}
 
 	ntedit_hip_ctx* ctx = nullptr;

@@ -98,20 +98,19 @@ make_dev_params(
 	    hp.max_insertions > 5 || hp.max_deletions > 10 || hp.mode < 0 || hp.mode > 2) {
 		return NTEDIT_E_ARG;
 	}
-	if (hp.snv) {
-		return NTEDIT_E_UNSUPPORTED;
-	}
 	nte::DevParams d;
 	memset(&d, 0, sizeof d);
 	d.k = k;
 	d.h = hash_num;
 	d.jump = hp.jump;
-	d.ins_tries = num_tries[hp.max_insertions];
-	d.max_deletions = hp.max_deletions;
+	// ntedit.cpp:2411-2413: -s 1 switches the indel sweep off
+	d.ins_tries = hp.snv ? 0 : num_tries[hp.max_insertions];
+	d.max_deletions = hp.snv ? 0 : hp.max_deletions;
 	d.mode = (uint32_t)hp.mode;
 	d.mask = hp.mask ? 1 : 0;
 	d.secbf = secbf ? 1 : 0;
 	d.counting = counting ? 1 : 0;
+	d.snv = hp.snv ? 1 : 0;
 	// ntedit.cpp:2453-2458: -p only exists for counting filters
 	d.min_thr = counting ? hp.min_threshold : 1;
 	d.max_thr = counting ? hp.max_threshold : 255;

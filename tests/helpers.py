@@ -190,7 +190,7 @@ def run_hostsim(recs, bf, params, out_prefix, rep=None):
 def oracle_args(params):
     a = ["-z", str(params.min_contig_len), "-i", str(params.max_insertions), "-d", str(params.max_deletions),
          "-j", str(params.jump), "-m", str(params.mode), "-a", str(params.mask),
-         "-p", str(params.min_threshold), "-q", str(params.max_threshold)]
+         "-p", str(params.min_threshold), "-q", str(params.max_threshold), "-s", str(params.snv)]
     if params.use_ratio:
         a += ["-X", repr(float(params.missing_ratio)), "-Y", repr(float(params.edit_ratio))]
     else:
@@ -297,6 +297,12 @@ def make_case(tmp, seed, n=60000, p_sub=2e-3, p_ins=3e-4, p_del=3e-4, k=25, hash
         if "lower" in flavor:
             q = int(rng.integers(0, len(d) - 5000))
             d[q:q + 3000] = bytes(d[q:q + 3000]).lower()
+        if "exotic" in flavor:
+            # bytes that are not accepted bases but carry ntHash seeds (U hashes like T; '-', '5', ... pick up a
+            # complement-slot seed through c & 7); placed close to errors so that indel sweeps hash across them
+            for _ in range(60):
+                q = int(rng.integers(0, len(d)))
+                d[q] = b"Uu-*5!1="[int(rng.integers(0, 8))]
         if "iupac" in flavor:
             for _ in range(20):
                 q = int(rng.integers(0, len(d)))
@@ -341,6 +347,12 @@ PARITY_CONFIGS = [
     (dict(hashes=4, bfbytes=100003 * 8), dict()),
     (dict(hashes=1, bfbytes=1 << 18), dict()),
     (dict(hashes=6, bfbytes=(1 << 18) + 8), dict()),
+    (dict(flavor="exotic", p_sub=5e-3, p_ins=2e-3, p_del=2e-3), dict(max_deletions=10)),
+    (dict(flavor="exotic N", p_sub=5e-3, p_ins=2e-3, p_del=2e-3), dict(mode=2, max_insertions=3, max_deletions=6)),
+    # SNV mode: every position re-assessed
+    (dict(n=8000, contigs=2), dict(snv=1)),
+    (dict(n=8000, contigs=2, flavor="N iupac lower"), dict(snv=1, mode=2, mask=1)),
+    (dict(n=8000, contigs=2, flavor="cbf"), dict(snv=1, min_threshold=2)),
     # counting Bloom filters (KmerCountingBloomFilter8): -p / -q thresholds, coverage medians
     (dict(flavor="cbf"), dict()),
     (dict(flavor="cbf"), dict(min_threshold=2)),

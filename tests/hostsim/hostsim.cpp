@@ -45,7 +45,7 @@ sim_screen(const u8* seq, u64 n, const Filter& f, const DevParams& p, const u64*
 		hash_roll(hs, tab, out, in);
 		good = in == CODE_BAD ? 0 : good + 1;
 		if (good >= p.k) {
-			if (filter_screen_absent(f, p, hs)) {
+			if (p.snv || filter_screen_absent(f, p, hs)) {
 				u64 s = i + 1 - p.k;
 				bitmap[s >> 6] |= 1ULL << (s & 63);
 			}
@@ -123,7 +123,7 @@ hostsim_polish(
 		}
 	}
 	// arena: generous
-	u32 arena_chunks = (u32)(events.size() * 4 + n / 8 + 1024);
+	u32 arena_chunks = (u32)(events.size() * 4 + n + 1024);
 	std::vector<Item> arena((size_t)arena_chunks * CHUNK_ITEMS);
 	u32 arena_next = 0;
 	std::vector<Node> nodes(p.node_window);

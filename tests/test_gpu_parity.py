@@ -55,7 +55,7 @@ def test_polish_matches_oracle(tmp_path, ci, oracle_build):
     assert st.events >= st.events_applied
 
 
-@pytest.mark.parametrize("ci", [0, 1, 3, 16, 23, 24, 25, 26, 27, 28, 29])
+@pytest.mark.parametrize("ci", [0, 1, 3, 16, 23, 24, 25, 26, 31, 32, 33, 34])
 def test_screen_bitmap_matches_oracle(tmp_path, ci, polisher, oracle_build):
     case_kw, par_kw = H.PARITY_CONFIGS[ci]
     case = H.make_case(str(tmp_path), 2000 + ci, **case_kw)

@@ -220,3 +220,40 @@ def test_golden_cases_on_gpu(tmp_path):
             pol.close()
         assert filecmp.cmp(os.path.join(d, "expected_changes.tsv"), str(tmp_path / (name + "_changes.tsv")), shallow=False), name
         assert filecmp.cmp(os.path.join(d, "expected_edited.fa"), str(tmp_path / (name + "_edited.fa")), shallow=False), name
+
+
+def test_cli_drop_in(tmp_path, oracle_build):
+    """the `ntedit` host binary: reference flag surface, gzipped multi-FASTA with comments and a
+    short contig, default output prefix (ntedit.cpp:2496-2502), -e, outputs byte-identical to the oracle"""
+    import gzip
+    import shutil
+    import subprocess
+    cli = os.path.join(H.ROOT, "ntedit_amd", "ntedit")
+    assert os.path.exists(cli), "build the CLI first (make -C ntedit_amd/csrc)"
+    case = H.make_case(str(tmp_path), 7001, flavor="sec N lower", contigs=4, n=40000)
+    gz = str(tmp_path / "draft.fa.gz")
+    with open(case["draft"], "rb") as fi, gzip.open(gz, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    hp = H.default_params(max_insertions=4, max_deletions=7, mode=1, min_contig_len=50)
+    H.run_oracle(gz, case["bf"], hp, str(tmp_path / "o"), case["rep"])
+    r = subprocess.run([cli, "-f", gz, "-r", case["bf"], "-e", case["rep"], "-i", "4", "-d", "7", "-m", "1", "-z", "50",
+                        "-k", "99", "-t", "48", "-c", "3", "-v", "0", "--batch-bases", "70000", "--report"],
+                       cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    prefix = "draft.fa.gz_k25_z50_rt.bf_i4_d7_m1"  # <draft>_k<k>_z<z>_r<bf>_i<i>_d<d>_m<m>
+    assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / (prefix + "_changes.tsv")), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / (prefix + "_edited.fa")), shallow=False)
+    vcf = open(str(tmp_path / (prefix + "_variants.vcf"))).read().splitlines()
+    assert vcf[0] == "##fileformat=VCFv4.2" and vcf[-1].startswith("#CHROM\tPOS")
+    # parameter clamping messages (ntedit.cpp:2485-2493) and a counting filter with -p/-q
+    case2 = H.make_case(str(tmp_path / "c2"), 7002, flavor="cbf", contigs=2, n=20000)
+    hp2 = H.default_params(min_threshold=2, max_threshold=5)
+    H.run_oracle(case2["draft"], case2["bf"], hp2, str(tmp_path / "o2"))
+    r = subprocess.run([cli, "-f", case2["draft"], "-r", case2["bf"], "-b", str(tmp_path / "g2"), "-i", "9", "-d", "12",
+                        "-p", "2", "-q", "5"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "i parameter too high" in r.stderr and "d parameter too high" in r.stderr
+    H.run_oracle(case2["draft"], case2["bf"], H.default_params(min_threshold=2, max_threshold=5, max_insertions=9,
+                                                               max_deletions=12), str(tmp_path / "o3"))
+    assert filecmp.cmp(str(tmp_path / "o3_changes.tsv"), str(tmp_path / "g2_changes.tsv"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "o3_edited.fa"), str(tmp_path / "g2_edited.fa"), shallow=False)

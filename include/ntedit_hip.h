@@ -162,7 +162,7 @@ typedef struct ntedit_hip_stats
 int ntedit_hip_result_stats(const ntedit_hip_result* r, ntedit_hip_stats* s);
 
 /* Host-side rendering of a result (replaces writeEditsToFile, ntedit.cpp:925-1213,
- * for _edited.fa and _changes.tsv; the VCF body is outside the parity contract).
+ * for _edited.fa and _changes.tsv; write_outputs_vcf() adds _variants.vcf).
  * bases/offsets/lens: the same batch, in HOST memory.  names[i] is the FASTA
  * header text (name + " " + comment, ntedit.cpp:2224-2229).  Files are opened
  * in append mode when append != 0; the TSV header is written by
@@ -178,6 +178,29 @@ int ntedit_hip_write_outputs(
     const char* tsv_path,
     int append);
 int ntedit_hip_write_tsv_header(const char* tsv_path, uint32_t k, uint32_t jump, int counting);
+
+/* _variants.vcf (ntedit.cpp:951-977, 986-1162, 1184-1208; header 2192-2211) and the -l
+ * annotation map (vcf_entry_to_map, ntedit.cpp:2261-2274; plain or gzipped input).
+ * write_outputs_vcf = write_outputs + the VCF body; snv = the -s flag the batch was polished
+ * with (in SNV mode unedited positions with supported alternatives are VCF-only records);
+ * annot may be NULL (every annotation reads "NA"). */
+typedef struct ntedit_hip_annot ntedit_hip_annot;
+int ntedit_hip_annot_load(const char* vcf_path, ntedit_hip_annot** out);
+void ntedit_hip_annot_free(ntedit_hip_annot* a);
+int ntedit_hip_write_vcf_header(const char* vcf_path, const char* draft_filename);
+int ntedit_hip_write_outputs_vcf(
+    const ntedit_hip_result* r,
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    const char* fa_path,
+    const char* tsv_path,
+    const char* vcf_path,
+    int append,
+    int snv,
+    const ntedit_hip_annot* annot);
 
 /* timings of the last screen()/filter_insert() call (HIP events, ms) */
 float ntedit_hip_last_kernel_ms(const ntedit_hip_ctx* ctx);

@@ -1325,8 +1325,48 @@ ntedit_hip_result_stats(const ntedit_hip_result* r, ntedit_hip_stats* s)
 	return 0;
 }
 
+struct ntedit_hip_annot
+{
+	nte_host::Annotations* a = nullptr;
+};
+
 int
-ntedit_hip_write_outputs(
+ntedit_hip_annot_load(const char* vcf_path, ntedit_hip_annot** out)
+{
+	if (!vcf_path || !out) {
+		return NTEDIT_E_ARG;
+	}
+	nte_host::Annotations* a = nte_host::annotations_load(vcf_path);
+	if (!a) {
+		return NTEDIT_E_IO;
+	}
+	*out = new ntedit_hip_annot();
+	(*out)->a = a;
+	return 0;
+}
+
+void
+ntedit_hip_annot_free(ntedit_hip_annot* a)
+{
+	if (a) {
+		nte_host::annotations_free(a->a);
+		delete a;
+	}
+}
+
+int
+ntedit_hip_write_vcf_header(const char* vcf_path, const char* draft_filename)
+{
+	FILE* v = fopen(vcf_path, "wb");
+	if (!v) {
+		return NTEDIT_E_IO;
+	}
+	nte_host::write_vcf_header(v, draft_filename ? draft_filename : "");
+	return fclose(v) == 0 ? 0 : NTEDIT_E_IO;
+}
+
+int
+ntedit_hip_write_outputs_vcf(
     const ntedit_hip_result* r,
     const char* bases,
     const uint64_t* offsets,
@@ -1335,19 +1375,26 @@ ntedit_hip_write_outputs(
     uint32_t n_contigs,
     const char* fa_path,
     const char* tsv_path,
-    int append)
+    const char* vcf_path,
+    int append,
+    int snv,
+    const ntedit_hip_annot* annot)
 {
 	if (!r || (n_contigs && (!bases || !offsets || !lens || !names))) {
 		return NTEDIT_E_ARG;
 	}
 	FILE* fa = fa_path ? fopen(fa_path, append ? "ab" : "wb") : nullptr;
 	FILE* tsv = tsv_path ? fopen(tsv_path, append ? "ab" : "wb") : nullptr;
-	if ((fa_path && !fa) || (tsv_path && !tsv)) {
+	FILE* vcf = vcf_path ? fopen(vcf_path, append ? "ab" : "wb") : nullptr;
+	if ((fa_path && !fa) || (tsv_path && !tsv) || (vcf_path && !vcf)) {
 		if (fa) {
 			fclose(fa);
 		}
 		if (tsv) {
 			fclose(tsv);
+		}
+		if (vcf) {
+			fclose(vcf);
 		}
 		return NTEDIT_E_IO;
 	}
@@ -1357,8 +1404,14 @@ ntedit_hip_write_outputs(
 	if (tsv) {
 		setvbuf(tsv, nullptr, _IOFBF, 1 << 20);
 	}
+	if (vcf) {
+		setvbuf(vcf, nullptr, _IOFBF, 1 << 20);
+	}
 	ntedit_hip_result* rw = const_cast<ntedit_hip_result*>(r);
 	rw->rst = nte_host::RenderStats();
+	nte_host::RenderOptions opt;
+	opt.snv = snv != 0;
+	opt.annot = annot ? annot->a : nullptr;
 	int rc = nte_host::render_batch(
 	    (const Item*)r->arena_buf.p,
 	    r->arena_items,
@@ -1371,14 +1424,34 @@ ntedit_hip_write_outputs(
 	    n_contigs,
 	    fa,
 	    tsv,
-	    &rw->rst);
+	    &rw->rst,
+	    vcf,
+	    &opt);
 	if (fa && fclose(fa) != 0) {
 		rc = rc ? rc : NTEDIT_E_IO;
 	}
 	if (tsv && fclose(tsv) != 0) {
 		rc = rc ? rc : NTEDIT_E_IO;
 	}
+	if (vcf && fclose(vcf) != 0) {
+		rc = rc ? rc : NTEDIT_E_IO;
+	}
 	return rc ? NTEDIT_E_IO : 0;
+}
+
+int
+ntedit_hip_write_outputs(
+    const ntedit_hip_result* r,
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    const char* fa_path,
+    const char* tsv_path,
+    int append)
+{
+	return ntedit_hip_write_outputs_vcf(r, bases, offsets, lens, names, n_contigs, fa_path, tsv_path, nullptr, append, 0, nullptr);
 }
 
 int

@@ -1550,6 +1550,17 @@ struct Machine
 				}
 				changelast(hs, draft_char, lc);
 			}
+			if (p.snv && b.altsupp1) {
+				// -s 1: a position that keeps its base but has supported alternatives is still
+				// reported (VCF only): sub_base == draft_char marks "no edit" (ntedit.cpp:1428-1443)
+				Item it;
+				it.w[0] = TAG_SUB | ((u32)draft_char << 8) | ((u32)draft_char << 16) | ((b.num_support & 0xFF) << 24);
+				it.w[1] = t_seq_i;
+				it.w[2] = (u32)b.altbase1 | ((b.altsupp1 & 0xFF) << 8) | ((u32)b.altbase2 << 16) |
+				          ((b.altsupp2 & 0xFF) << 24);
+				it.w[3] = (u32)b.altbase3 | ((b.altsupp3 & 0xFF) << 8);
+				emit(it);
+			}
 			break;
 		default:
 			break;

@@ -149,35 +149,67 @@ def _split_fasta_records(path):
 
 
 def merge_shards(records, parts, out_prefix, min_len):
-    """Host-side gather: interleave the shard outputs back into input order."""
+    """Host-side gather: interleave the shard outputs back into input order.  _edited.fa has two
+    lines per contig; _changes.tsv / _variants.vcf rows carry the contig header in column 1 and are
+    contiguous per contig inside a shard."""
     world = len(parts)
     fa = [_split_fasta_records("%s.shard%d_edited.fa" % (out_prefix, r)) for r in range(world)]
-    tsv_header = None
-    rows = []
-    for r in range(world):
-        with open("%s.shard%d_changes.tsv" % (out_prefix, r), "rb") as f:
-            lines = f.read().split(b"\n")
-        tsv_header = lines[0]
-        rows.append([l for l in lines[1:] if l])
+
+    def load_rows(suffix, is_header):
+        header, rows = None, []
+        for r in range(world):
+            path = "%s.shard%d%s" % (out_prefix, r, suffix)
+            if not os.path.exists(path):
+                return None, None
+            with open(path, "rb") as f:
+                lines = [l for l in f.read().split(b"\n") if l]
+            hd = [l for l in lines if is_header(l)]
+            if r == 0:
+                header = hd
+            rows.append([l for l in lines if not is_header(l)])
+        return header, rows
+
+    first_tsv = [True]
+
+    def tsv_header(l):
+        return l.startswith(b"ID\tbpPosition+1\t")
+
+    tsv_hdr, tsv_rows = load_rows("_changes.tsv", tsv_header)
+    vcf_hdr, vcf_rows = load_rows("_variants.vcf", lambda l: l.startswith(b"#"))
     owner = {}
     for r in range(world):
         for j, i in enumerate(parts[r]):
             owner[int(i)] = (r, j)
-    # TSV rows of one contig are contiguous in its shard file, keyed by the contig header
-    cursor = [0] * world
+    cur_t = [0] * world
+    cur_v = [0] * world
+    ovcf = open(out_prefix + "_variants.vcf", "wb") if vcf_rows is not None else None
     with open(out_prefix + "_edited.fa", "wb") as ofa, open(out_prefix + "_changes.tsv", "wb") as otsv:
-        otsv.write(tsv_header + b"\n")
+        for l in tsv_hdr:
+            otsv.write(l + b"\n")
+        if ovcf:
+            for l in vcf_hdr:
+                ovcf.write(l + b"\n")
         for i, (hdr, seq) in enumerate(records):
             if i not in owner:
                 continue
             r, j = owner[i]
             ofa.write(fa[r][j])
             key = bytes(hdr) + b"\t"
-            c = cursor[r]
-            while c < len(rows[r]) and rows[r][c].startswith(key):
-                otsv.write(rows[r][c] + b"\n")
+            c = cur_t[r]
+            while c < len(tsv_rows[r]) and tsv_rows[r][c].startswith(key):
+                otsv.write(tsv_rows[r][c] + b"\n")
                 c += 1
-            cursor[r] = c
+            cur_t[r] = c
+            if ovcf:
+                c = cur_v[r]
+                while c < len(vcf_rows[r]) and vcf_rows[r][c].startswith(key):
+                    ovcf.write(vcf_rows[r][c] + b"\n")
+                    c += 1
+                cur_v[r] = c
+    if ovcf:
+        ovcf.close()
     for r in range(world):
-        os.remove("%s.shard%d_edited.fa" % (out_prefix, r))
-        os.remove("%s.shard%d_changes.tsv" % (out_prefix, r))
+        for suffix in ("_edited.fa", "_changes.tsv", "_variants.vcf"):
+            path = "%s.shard%d%s" % (out_prefix, r, suffix)
+            if os.path.exists(path):
+                os.remove(path)

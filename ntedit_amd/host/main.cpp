@@ -8,8 +8,8 @@
 // i.e. the reference at -t 1).  Reads the draft with kseq semantics, batches
 // contigs, calls the C ABI (include/ntedit_hip.h) and writes
 // <prefix>_edited.fa and <prefix>_changes.tsv byte-identically to the
-// reference.  <prefix>_variants.vcf gets the reference's header lines only
-// (the VCF body is outside this path's parity contract).
+// reference, plus <prefix>_variants.vcf (the ##fileDate line carries today's date, as in
+// the reference).
 #include "../../include/ntedit_hip.h"
 #include "fasta.h"
 
@@ -45,7 +45,7 @@ static const char USAGE[] = PROGRAM
     "	-j, 	controls size of k-mer subset, check every jth k-mer, [default=3]\n"
     "	-m,	mode of editing, range 0-2, [default=0]\n"
     "	-s,     SNV mode. Overrides draft k-mer checks, forcing reassessment at each position (-s 1 = yes, default = 0, no)\n"
-    "	-l,	input VCF file with annotated variants (accepted, unused on this path)\n"
+    "	-l,	input VCF file with annotated variants (e.g., clinvar.vcf[.gz]), OPTIONAL\n"
     "	-a,	soft masks missing k-mer positions having no fix (1 = yes, default = 0, no)\n"
     "	-v,	verbose mode (accepted)\n"
     "	-p,	minimum k-mer coverage threshold (CBF only) [default=1]\n"
@@ -275,7 +275,7 @@ main(int argc, char** argv)
 	if (p.snv) {
 		// ntedit.cpp:2411-2417
 		fprintf(stderr, "\nSNV mode ON\nTracking all single-base variants\nNote: -i and -d both set to 0 when -s is set to 1\n"
-		                "(this build writes _edited.fa and _changes.tsv; the VCF body is not produced)\n\n");
+		                "Consider -l clinvar.vcf to identify SNVs with putative clinical significance\n\n");
 	}
 
 	ntedit_hip_ctx* ctx = nullptr;
@@ -363,16 +363,17 @@ main(int argc, char** argv)
 		fprintf(stderr, PROGRAM ": error: cannot write `%s'\n", tsv_path.c_str());
 		exit(EXIT_FAILURE);
 	}
-	if (FILE* v = fopen(vcf_path.c_str(), "wb")) {
-		// ntedit.cpp:2192-2211 (header only; records are outside this path)
-		time_t now = time(nullptr);
-		tm* ltm = localtime(&now);
-		fprintf(v, "##fileformat=VCFv4.2\n##fileDate=%04d%02d%02d\n##source=" PROGRAM "\n##reference=file:%s\n",
-		        1900 + ltm->tm_year, 1 + ltm->tm_mon, ltm->tm_mday, draft.c_str());
-		fputs("##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n", v);
-		fputs("##INFO=<ID=AD,Number=2,Type=Integer,Description=\"Kmer Depth\">\n", v);
-		fputs("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tINTEGRATION\n", v);
-		fclose(v);
+	if (ntedit_hip_write_vcf_header(vcf_path.c_str(), draft.c_str()) != 0) { // ntedit.cpp:2192-2211
+		fprintf(stderr, PROGRAM ": error: cannot write `%s'\n", vcf_path.c_str());
+		exit(EXIT_FAILURE);
+	}
+	ntedit_hip_annot* annot = nullptr;
+	if (!vcf.empty()) {
+		// -l: annotated variants (e.g. clinvar.vcf[.gz]), ntedit.cpp:2524-2562
+		die_unreadable(vcf);
+		if (ntedit_hip_annot_load(vcf.c_str(), &annot) != 0) {
+			fprintf(stderr, "Unable to open file\n");
+		}
 	}
 
 	nte_host::FastaReader reader(draft.c_str());
@@ -402,8 +403,9 @@ main(int argc, char** argv)
 		for (size_t i = 0; i < b.names.size(); i++) {
 			names[i] = b.names[i].c_str();
 		}
-		rc = ntedit_hip_write_outputs(res, b.blob.data(), b.offs.data(), b.lens.data(), names.data(),
-		                              (uint32_t)names.size(), fa_path.c_str(), tsv_path.c_str(), 1);
+		rc = ntedit_hip_write_outputs_vcf(res, b.blob.data(), b.offs.data(), b.lens.data(), names.data(),
+		                                  (uint32_t)names.size(), fa_path.c_str(), tsv_path.c_str(), vcf_path.c_str(), 1,
+		                                  p.snv, annot);
 		if (rc != 0) {
 			fprintf(stderr, PROGRAM ": error: cannot write outputs\n");
 			exit(EXIT_FAILURE);
@@ -465,6 +467,7 @@ main(int argc, char** argv)
 		       (unsigned long long)tot.substitutions, (unsigned long long)tot.insertions,
 		       (unsigned long long)tot.deletions);
 	}
+	ntedit_hip_annot_free(annot);
 	ntedit_hip_destroy(ctx);
 	return 0;
 }

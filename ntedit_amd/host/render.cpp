@@ -1,13 +1,100 @@
 // render.cpp -- see render.h.  Host-side, single pass over the batch.
 #include "render.h"
 
+#include <cctype>
 #include <cmath>
 #include <cstring>
+#include <ctime>
+#include <map>
 #include <string>
+#include <zlib.h>
 
 namespace nte_host {
 
 using nte::Item;
+
+// ------------------------------------------------------------ -l annotations
+class Annotations
+{
+  public:
+	std::map<std::string, std::string> m;
+	// "^" + INFO of the variant id, or "^NA" (clinvar[id].empty() -> NA in the reference)
+	void put(FILE* vcf, const std::string& id) const
+	{
+		auto it = m.find(id);
+		fputc('^', vcf);
+		if (it != m.end() && !it->second.empty()) {
+			fputs(it->second.c_str(), vcf);
+		} else {
+			fputs("NA", vcf);
+		}
+	}
+};
+
+Annotations*
+annotations_load(const char* path)
+{
+	gzFile f = gzopen(path, "r");
+	if (!f) {
+		return nullptr;
+	}
+	Annotations* a = new Annotations();
+	std::string line;
+	char buf[1 << 16];
+	auto flush = [&]() {
+		// vcf_entry_to_map (ntedit.cpp:2261-2274): >= 8 tab-separated fields
+		std::string tok[8];
+		size_t nt = 0, start = 0;
+		for (size_t i = 0; i <= line.size() && nt < 8; i++) {
+			if (i == line.size() || line[i] == '\t') {
+				tok[nt++] = line.substr(start, i - start);
+				start = i + 1;
+			}
+		}
+		if (nt >= 8) {
+			a->m[tok[0] + ">" + tok[3] + tok[1] + tok[4]] = tok[7];
+		}
+		line.clear();
+	};
+	while (gzgets(f, buf, sizeof buf)) {
+		line += buf;
+		if (!line.empty() && line.back() == '\n') {
+			line.pop_back();
+			flush();
+		}
+	}
+	if (!line.empty()) {
+		flush();
+	}
+	gzclose(f);
+	return a;
+}
+
+void
+annotations_free(Annotations* a)
+{
+	delete a;
+}
+
+static void
+put_annot(FILE* vcf, const Annotations* a, const std::string& id)
+{
+	if (a) {
+		a->put(vcf, id);
+	} else {
+		fputs("^NA", vcf);
+	}
+}
+
+static std::string
+upper(const char* s, size_t n)
+{
+	std::string r(s, n);
+	for (char& c : r) {
+		c = (char)toupper((unsigned char)c);
+	}
+	return r;
+}
 
 namespace {
 
@@ -36,6 +123,98 @@ struct ContigState
 	bool terminated = false;
 };
 
+// the substitution line of _variants.vcf (ntedit.cpp:986-1162)
+void
+write_vcf_substitution(FILE* vcf, const std::string& H, const RSub& s, const RenderOptions& opt, bool is_edit)
+{
+	std::string base(1, (char)s.sub);
+	std::string support = std::to_string(s.support);
+	const char D = (char)toupper(s.draft);
+	const std::string pos1 = std::to_string(s.pos + 1);
+	std::vector<std::string> ids;
+	ids.push_back(H + ">" + D + pos1 + D);
+	if (is_edit) {
+		ids.push_back(H + ">" + D + pos1 + (char)toupper((unsigned char)base[0]));
+	}
+	uint8_t ab[3];
+	uint32_t as[3];
+	int na = 0;
+	if (s.s1 > 0) {
+		ab[na] = s.a1;
+		as[na++] = s.s1;
+	}
+	if (s.s2 > 0) {
+		ab[na] = s.a2;
+		as[na++] = s.s2;
+	}
+	if (s.s3 > 0) {
+		ab[na] = s.a3;
+		as[na++] = s.s3;
+	}
+	uint32_t curr_best = 0;
+	char best_alt_base = '1';
+	const char* genotype = "1/1";
+	if (na) {
+		if (opt.snv) {
+			if (!is_edit) {
+				for (int i = 0; i < na; i++) {
+					if (as[i] > curr_best) {
+						curr_best = as[i];
+						best_alt_base = (char)ab[i];
+					}
+				}
+				base = std::string(1, best_alt_base);
+				ids.push_back(H + ">" + D + pos1 + (char)toupper((unsigned char)best_alt_base));
+				support += "," + std::to_string(curr_best);
+				genotype = "0/1";
+			} else {
+				bool ref = false;
+				for (int i = 0; i < na; i++) {
+					if (s.draft == ab[i]) {
+						curr_best = as[i];
+						ref = true;
+						break;
+					}
+					if (as[i] > curr_best) {
+						curr_best = as[i];
+						best_alt_base = (char)ab[i];
+					}
+				}
+				if (ref) {
+					support = std::to_string(curr_best) + "," + support;
+					genotype = "0/1";
+				} else {
+					genotype = "1/2";
+					support += "," + std::to_string(curr_best);
+					base += ",";
+					base += best_alt_base;
+					ids.push_back(H + ">" + D + pos1 + (char)toupper((unsigned char)best_alt_base));
+				}
+			}
+		} else {
+			for (int i = 0; i < na; i++) {
+				if (s.draft == ab[i]) {
+					continue;
+				}
+				if (as[i] > curr_best) {
+					curr_best = as[i];
+					best_alt_base = (char)ab[i];
+				}
+			}
+			genotype = "1/2";
+			support += "," + std::to_string(curr_best);
+			base += ",";
+			base += best_alt_base;
+			ids.push_back(H + ">" + D + pos1 + (char)toupper((unsigned char)best_alt_base));
+		}
+	}
+	fprintf(vcf, "%s\t%u\t.\t%c\t%s\t.\tPASS\tAD=%s", H.c_str(), s.pos + 1, s.draft, base.c_str(), support.c_str());
+	for (const std::string& id : ids) {
+		put_annot(vcf, opt.annot, id);
+	}
+	fprintf(vcf, "\tGT\t%s\n", genotype);
+}
+
 // Writes one record the way writeEditsToFile walks the rope (ntedit.cpp:936-1212).
 void
 write_contig(
@@ -45,8 +224,11 @@ write_contig(
     const std::vector<RSub>& subs,
     FILE* fa,
     FILE* tsv,
-    RenderStats* st)
+    RenderStats* st,
+    FILE* vcf,
+    const RenderOptions& opt)
 {
+	const std::string H(hdr);
 	if (fa) {
 		fputc('>', fa);
 		fputs(hdr, fa);
@@ -66,13 +248,24 @@ write_contig(
 				if (tsv) {
 					fprintf(tsv, "%s\t%u\t%c\t+%s\t%d\n", hdr, pos, draft_char, ins.c_str(), num_support);
 				}
+				if (vcf) {
+					// ntedit.cpp:954-977
+					const char D = (char)toupper(draft_char);
+					fprintf(vcf, "%s\t%u\t.\t%c\t%c%s\t.\tPASS\tAD=%d", hdr, pos, draft_char, draft_char, ins.c_str(), num_support);
+					put_annot(vcf, opt.annot, H + ">" + D + std::to_string(pos) + D + upper(ins.data(), ins.size()));
+					fputs("\tGT\t1/1\n", vcf);
+				}
 				st->insertions++;
 				ins.clear();
 				num_support = -1;
 			}
 			while (qi < subs.size() && subs[qi].pos <= cur.e_pos) {
 				const RSub& s = subs[qi];
-				if (tsv) {
+				const bool is_edit = !(opt.snv && s.draft == s.sub); // "snv_mode_no_edit" in the reference
+				if (vcf) {
+					write_vcf_substitution(vcf, H, s, opt, is_edit);
+				}
+				if (tsv && is_edit) {
 					fprintf(tsv, "%s\t%u\t%c\t%c\t%u", hdr, s.pos + 1, s.draft, s.sub, s.support);
 					if (s.s1 > 0) {
 						fprintf(tsv, "\t%c\t%u", s.a1, s.s1);
@@ -85,7 +278,9 @@ write_contig(
 					}
 					fputc('\n', tsv);
 				}
-				st->substitutions++;
+				if (is_edit) {
+					st->substitutions++;
+				}
 				qi++;
 			}
 			if (fa) {
@@ -110,6 +305,16 @@ write_contig(
 					fwrite(seq + pos, 1, (size_t)nx.s_pos - pos, tsv);
 					fprintf(tsv, "\t%u\n", nx.support);
 				}
+				if (vcf && pos > 0) {
+					// ntedit.cpp:1184-1208
+					const size_t dl = (size_t)(nx.s_pos - pos) + 1;
+					fprintf(vcf, "%s\t%u\t.\t", hdr, pos);
+					fwrite(seq + pos - 1, 1, dl, vcf);
+					fprintf(vcf, "\t%c\t.\tPASS\tAD=%u", seq[pos - 1], nx.support);
+					put_annot(vcf, opt.annot,
+					          H + ">" + upper(seq + pos - 1, dl) + std::to_string(pos) + (char)toupper((unsigned char)seq[pos - 1]));
+					fputs("\tGT\t1/1\n", vcf);
+				}
 				st->deletions++;
 			}
 		}
@@ -120,6 +325,18 @@ write_contig(
 }
 
 } // namespace
+
+void
+write_vcf_header(FILE* vcf, const char* draft_filename)
+{
+	time_t now = time(nullptr);
+	tm* ltm = localtime(&now);
+	fprintf(vcf, "##fileformat=VCFv4.2\n##fileDate=%04d%02d%02d\n##source=ntEdit v2.1.1\n##reference=file:%s\n",
+	        1900 + ltm->tm_year, 1 + ltm->tm_mon, ltm->tm_mday, draft_filename);
+	fputs("##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n", vcf);
+	fputs("##INFO=<ID=AD,Number=2,Type=Integer,Description=\"Kmer Depth\">\n", vcf);
+	fputs("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tINTEGRATION\n", vcf);
+}
 
 void
 write_tsv_header(FILE* tsv, uint32_t k, uint32_t jump, bool counting)
@@ -148,8 +365,11 @@ render_batch(
     uint32_t n_contigs,
     FILE* fa,
     FILE* tsv,
-    RenderStats* stats)
+    RenderStats* stats,
+    FILE* vcf,
+    const RenderOptions* opt_in)
 {
+	const RenderOptions opt = opt_in ? *opt_in : RenderOptions();
 	RenderStats local;
 	RenderStats* st = stats ? stats : &local;
 	size_t ev = 0;
@@ -276,7 +496,7 @@ render_batch(
 			}
 			continue;
 		}
-		write_contig(names[ci], out_seq, cs.nodes, cs.subs, fa, tsv, st);
+		write_contig(names[ci], out_seq, cs.nodes, cs.subs, fa, tsv, st, vcf, opt);
 	}
 	return 0;
 }

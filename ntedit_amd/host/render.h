@@ -19,6 +19,17 @@ struct RenderStats
 	uint64_t deletions = 0;
 };
 
+// -l annotation map (ntedit.cpp:2261-2274,2524-2562): "CHROM>REF POS ALT" -> INFO
+class Annotations;
+Annotations* annotations_load(const char* path); // plain or gzipped VCF; nullptr if unreadable
+void annotations_free(Annotations* a);
+
+struct RenderOptions
+{
+	bool snv = false;               // -s 1: "no edit" substitution records go to the VCF only
+	const Annotations* annot = nullptr;
+};
+
 // arena:    host copy of the chunk arena
 // ev_first: first chunk of every event that produced output, ordered by
 //           global start position (contig order, then position)
@@ -35,7 +46,12 @@ int render_batch(
     uint32_t n_contigs,
     FILE* fa,
     FILE* tsv,
-    RenderStats* stats);
+    RenderStats* stats,
+    FILE* vcf = nullptr,
+    const RenderOptions* opt = nullptr);
+
+// ntedit.cpp:2192-2211
+void write_vcf_header(FILE* vcf, const char* draft_filename);
 
 void write_tsv_header(FILE* tsv, uint32_t k, uint32_t jump, bool counting);
 

@@ -54,14 +54,15 @@ class Result:
         self._lib.ntedit_hip_result_stats(self._h, ctypes.byref(s))
         return s
 
-    def write(self, blob, offsets, lens, names, fa_path, tsv_path, append=False):
+    def write(self, blob, offsets, lens, names, fa_path, tsv_path, append=False, vcf_path=None, snv=False, annot=None):
         n = len(names)
         arr = (ctypes.c_char_p * max(n, 1))(*names)
         buf = blob if isinstance(blob, (bytes, bytearray)) else bytes(blob)
-        rc = self._lib.ntedit_hip_write_outputs(
+        rc = self._lib.ntedit_hip_write_outputs_vcf(
             self._h, ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p),
             offsets.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), arr, n,
-            fa_path.encode() if fa_path else None, tsv_path.encode() if tsv_path else None, 1 if append else 0)
+            fa_path.encode() if fa_path else None, tsv_path.encode() if tsv_path else None,
+            vcf_path.encode() if vcf_path else None, 1 if append else 0, 1 if snv else 0, annot)
         if rc:
             raise NtEditHipError("write_outputs failed (%d)" % rc)
 
@@ -180,19 +181,27 @@ class Polisher:
         self._check(rc, "polish_batch")
         return Result(self._lib, res)
 
-    def polish_records(self, records, out_prefix):
+    def polish_records(self, records, out_prefix, draft_name="", annot_path=None):
         """readAndCorrect at -t 1 for an in-memory list of (header, sequence): writes
-        <prefix>_edited.fa and <prefix>_changes.tsv; returns Stats."""
+        <prefix>_edited.fa, <prefix>_changes.tsv and <prefix>_variants.vcf; returns Stats."""
         blob, offs, lens, names = pack_batch(records, self.params.min_contig_len)
         k, h, _, counting = self.filter_info(PRIMARY)
         tsv = out_prefix + "_changes.tsv"
         fa = out_prefix + "_edited.fa"
+        vcf = out_prefix + "_variants.vcf"
         rc = self._lib.ntedit_hip_write_tsv_header(tsv.encode(), k, self.params.jump, int(counting))
         if rc:
             raise NtEditHipError("cannot write %s" % tsv)
+        self._lib.ntedit_hip_write_vcf_header(vcf.encode(), draft_name.encode())
         open(fa, "wb").close()
+        annot = ctypes.c_void_p()
+        if annot_path:
+            if self._lib.ntedit_hip_annot_load(annot_path.encode(), ctypes.byref(annot)):
+                raise NtEditHipError("cannot read %s" % annot_path)
         res = self.polish_batch(blob, offs, lens)
-        res.write(blob, offs, lens, names, fa, tsv, append=True)
+        res.write(blob, offs, lens, names, fa, tsv, append=True, vcf_path=vcf, snv=bool(self.params.snv), annot=annot)
+        if annot_path:
+            self._lib.ntedit_hip_annot_free(annot)
         st = res.stats()
         res.free()
         return st

@@ -21,6 +21,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <zlib.h>
 
 ora_counters ora_ctr = { 0, 0, 0 };
@@ -868,10 +869,158 @@ roll(
 	return 1;
 }
 
+/* ------------------------------------------------ variant annotation map (-l) */
+/* ntedit.cpp:2261-2274,2524-2562: every line of the -l VCF with >= 8 tab-separated fields
+ * maps "CHROM>REF POS ALT" (concatenated, no blanks) to its INFO field */
+struct ora_annot
+{
+	char** key;
+	char** val;
+	size_t n, cap;
+	int sorted;
+};
+
+ora_annot*
+ora_annot_load(const char* path)
+{
+	gzFile f = gzopen(path, "r"); /* plain or gzipped (the reference uses Boost for .gz) */
+	if (!f) {
+		return NULL;
+	}
+	ora_annot* m = (ora_annot*)calloc(1, sizeof(*m));
+	size_t cap = 1 << 16;
+	char* line = (char*)malloc(cap);
+	for (;;) {
+		size_t n = 0;
+		int got = 0;
+		while (gzgets(f, line + n, (int)(cap - n))) {
+			got = 1;
+			n += strlen(line + n);
+			if (n && line[n - 1] == '\n') {
+				break;
+			}
+			if (cap - n < 2) {
+				cap *= 2;
+				line = (char*)realloc(line, cap);
+			}
+		}
+		if (!got) {
+			break;
+		}
+		while (n && (line[n - 1] == '\n')) {
+			line[--n] = 0;
+		}
+		/* split on tabs */
+		char* tok[9];
+		int nt = 0;
+		char* s = line;
+		tok[nt++] = s;
+		for (char* q = line; *q; q++) {
+			if (*q == '\t') {
+				*q = 0;
+				if (nt < 9) {
+					tok[nt++] = q + 1;
+				} else {
+					nt++;
+				}
+			}
+		}
+		if (nt >= 8) {
+			size_t kl = strlen(tok[0]) + 1 + strlen(tok[3]) + strlen(tok[1]) + strlen(tok[4]) + 1;
+			char* key = (char*)malloc(kl);
+			snprintf(key, kl, "%s>%s%s%s", tok[0], tok[3], tok[1], tok[4]);
+			if (m->n == m->cap) {
+				m->cap = m->cap ? m->cap * 2 : 1024;
+				m->key = (char**)realloc(m->key, m->cap * sizeof(char*));
+				m->val = (char**)realloc(m->val, m->cap * sizeof(char*));
+			}
+			m->key[m->n] = key;
+			m->val[m->n] = strdup(tok[7]);
+			m->n++;
+		}
+	}
+	free(line);
+	gzclose(f);
+	/* later duplicates overwrite earlier ones (std::map operator[]=): stable sort, keep the last */
+	if (m->n) {
+		size_t* idx = (size_t*)malloc(m->n * sizeof(size_t));
+		for (size_t i = 0; i < m->n; i++) {
+			idx[i] = i;
+		}
+		for (size_t i = 1; i < m->n; i++) { /* simple binary-insertion sort keeps it dependency-free */
+			size_t v = idx[i];
+			size_t lo = 0, hi = i;
+			while (lo < hi) {
+				size_t mid = (lo + hi) / 2;
+				if (strcmp(m->key[idx[mid]], m->key[v]) <= 0) {
+					lo = mid + 1;
+				} else {
+					hi = mid;
+				}
+			}
+			memmove(idx + lo + 1, idx + lo, (i - lo) * sizeof(size_t));
+			idx[lo] = v;
+		}
+		char** k2 = (char**)malloc(m->n * sizeof(char*));
+		char** v2 = (char**)malloc(m->n * sizeof(char*));
+		for (size_t i = 0; i < m->n; i++) {
+			k2[i] = m->key[idx[i]];
+			v2[i] = m->val[idx[i]];
+		}
+		free(m->key);
+		free(m->val);
+		free(idx);
+		m->key = k2;
+		m->val = v2;
+	}
+	m->sorted = 1;
+	return m;
+}
+
+void
+ora_annot_free(ora_annot* m)
+{
+	if (!m) {
+		return;
+	}
+	for (size_t i = 0; i < m->n; i++) {
+		free(m->key[i]);
+		free(m->val[i]);
+	}
+	free(m->key);
+	free(m->val);
+	free(m);
+}
+
+/* value of the LAST entry with this key, or NULL (empty values count as absent, like
+ * clinvar[id].empty() in the reference) */
+static const char*
+annot_get(const ora_annot* m, const char* key)
+{
+	if (!m || !m->n) {
+		return NULL;
+	}
+	size_t lo = 0, hi = m->n;
+	while (lo < hi) { /* upper bound */
+		size_t mid = (lo + hi) / 2;
+		if (strcmp(m->key[mid], key) <= 0) {
+			lo = mid + 1;
+		} else {
+			hi = mid;
+		}
+	}
+	if (lo == 0 || strcmp(m->key[lo - 1], key) != 0) {
+		return NULL;
+	}
+	return m->val[lo - 1][0] ? m->val[lo - 1] : NULL;
+}
+
 /* --------------------------------------------------------- polishing context */
 typedef struct
 {
 	const ora_params* p;
+	FILE* vcf;
+	const ora_annot* annot;
 	const ora_bf* bloom;
 	const ora_bf* bloomrep;
 	char* seq;
@@ -1444,10 +1593,142 @@ makeEdit(
 }
 
 /* ntedit.cpp:925-1213 (FASTA + TSV only; the VCF body is outside the parity contract) */
+/* "^" + annotation of the variant id, or "^NA" (ntedit.cpp:964-969 and the like) */
+static void
+vcf_annot(FILE* vcf, const ora_annot* m, const char* id)
+{
+	const char* v = annot_get(m, id);
+	fprintf(vcf, "^%s", v ? v : "NA");
+}
+
+static void
+upper_into(char* dst, const char* src, size_t n)
+{
+	for (size_t i = 0; i < n; i++) {
+		dst[i] = (char)toupper((unsigned char)src[i]);
+	}
+	dst[n] = 0;
+}
+
+/* the substitution line of the VCF (ntedit.cpp:986-1162) */
+static void
+vcf_substitution(FILE* vcf, const ora_annot* m, const char* hdr, const ora_params* p, const sRec* s)
+{
+	const int snv_mode_no_edit = !(p->snv && s->draft_char == s->sub_base);
+	char base[8];
+	char support[64];
+	char annot[4][16];
+	(void)annot;
+	size_t idcap = strlen(hdr) + 64;
+	char* id = (char*)malloc(idcap);
+	/* collected annotations are written at the end, in the reference's order */
+	const char* ann[3];
+	char* ann_owned[3] = { NULL, NULL, NULL };
+	int n_ann = 0;
+#define ADD_ANN(idstr)                                                                           \
+	do {                                                                                         \
+		const char* v_ = annot_get(m, (idstr));                                                  \
+		ann[n_ann++] = v_ ? v_ : "NA";                                                           \
+	} while (0)
+	snprintf(base, sizeof base, "%c", s->sub_base);
+	snprintf(support, sizeof support, "%u", s->num_support);
+	const char D = (char)toupper(s->draft_char);
+	snprintf(id, idcap, "%s>%c%u%c", hdr, D, s->pos + 1, D);
+	ADD_ANN(id);
+	if (snv_mode_no_edit) {
+		snprintf(id, idcap, "%s>%c%u%c", hdr, D, s->pos + 1, (char)toupper((unsigned char)base[0]));
+		ADD_ANN(id);
+	}
+	unsigned char ab[3];
+	unsigned as[3];
+	int na = 0;
+	if (s->altsupp1 > 0) {
+		ab[na] = s->altbase1;
+		as[na++] = s->altsupp1;
+	}
+	if (s->altsupp2 > 0) {
+		ab[na] = s->altbase2;
+		as[na++] = s->altsupp2;
+	}
+	if (s->altsupp3 > 0) {
+		ab[na] = s->altbase3;
+		as[na++] = s->altsupp3;
+	}
+	unsigned curr_best = 0;
+	char best_alt_base = '1';
+	const char* genotype;
+	if (na) {
+		if (p->snv) {
+			if (!snv_mode_no_edit) {
+				for (int i = 0; i < na; i++) {
+					if (as[i] > curr_best) {
+						curr_best = as[i];
+						best_alt_base = (char)ab[i];
+					}
+				}
+				snprintf(base, sizeof base, "%c", best_alt_base);
+				snprintf(id, idcap, "%s>%c%u%c", hdr, D, s->pos + 1, (char)toupper((unsigned char)best_alt_base));
+				ADD_ANN(id);
+				snprintf(support, sizeof support, "%u,%u", s->num_support, curr_best);
+				genotype = "0/1";
+			} else {
+				int ref = 0;
+				for (int i = 0; i < na; i++) {
+					if (s->draft_char == ab[i]) {
+						curr_best = as[i];
+						ref = 1;
+						break;
+					}
+					if (as[i] > curr_best) {
+						curr_best = as[i];
+						best_alt_base = (char)ab[i];
+					}
+				}
+				if (ref) {
+					snprintf(support, sizeof support, "%u,%u", curr_best, s->num_support);
+					genotype = "0/1";
+				} else {
+					genotype = "1/2";
+					snprintf(support, sizeof support, "%u,%u", s->num_support, curr_best);
+					snprintf(base, sizeof base, "%c,%c", s->sub_base, best_alt_base);
+					snprintf(id, idcap, "%s>%c%u%c", hdr, D, s->pos + 1, (char)toupper((unsigned char)best_alt_base));
+					ADD_ANN(id);
+				}
+			}
+		} else {
+			for (int i = 0; i < na; i++) {
+				if (s->draft_char == ab[i]) {
+					continue;
+				}
+				if (as[i] > curr_best) {
+					curr_best = as[i];
+					best_alt_base = (char)ab[i];
+				}
+			}
+			genotype = "1/2";
+			snprintf(support, sizeof support, "%u,%u", s->num_support, curr_best);
+			snprintf(base, sizeof base, "%c,%c", s->sub_base, best_alt_base);
+			snprintf(id, idcap, "%s>%c%u%c", hdr, D, s->pos + 1, (char)toupper((unsigned char)best_alt_base));
+			ADD_ANN(id);
+		}
+	} else {
+		genotype = "1/1";
+	}
+#undef ADD_ANN
+	fprintf(vcf, "%s\t%u\t.\t%c\t%s\t.\tPASS\tAD=%s", hdr, s->pos + 1, s->draft_char, base, support);
+	for (int i = 0; i < n_ann; i++) {
+		fprintf(vcf, "^%s", ann[i]);
+	}
+	fprintf(vcf, "\tGT\t%s\n", genotype);
+	(void)ann_owned;
+	free(id);
+}
+
 static void
 writeEditsToFile(FILE* fa, FILE* tsv, const char* hdr, ctx_t* c)
 {
 	const ora_params* p = c->p;
+	FILE* vcf = c->vcf;
 	nodeVec* nv = &c->nv;
 	recQueue* q = &c->subs;
 	const char* seq = c->seq;
@@ -1464,9 +1745,22 @@ writeEditsToFile(FILE* fa, FILE* tsv, const char* hdr, ctx_t* c)
 		if (curr.node_type == 0) {
 			if (n_ins) {
 				unsigned char draft_char = (unsigned char)seq[curr.s_pos - n_ins];
+				insertion_bases[n_ins] = 0;
 				if (tsv) {
-					insertion_bases[n_ins] = 0;
 					fprintf(tsv, "%s\t%u\t%c\t+%s\t%d\n", hdr, pos, draft_char, insertion_bases, num_support);
+				}
+				if (vcf) {
+					/* ntedit.cpp:954-977 */
+					size_t idcap = strlen(hdr) + n_ins + 64;
+					char* id = (char*)malloc(idcap);
+					char* up = (char*)malloc(n_ins + 2);
+					upper_into(up, insertion_bases, n_ins);
+					snprintf(id, idcap, "%s>%c%u%c%s", hdr, (char)toupper(draft_char), pos, (char)toupper(draft_char), up);
+					fprintf(vcf, "%s\t%u\t.\t%c\t%c%s\t.\tPASS\tAD=%d", hdr, pos, draft_char, draft_char, insertion_bases, num_support);
+					vcf_annot(vcf, c->annot, id);
+					fprintf(vcf, "\tGT\t1/1\n");
+					free(id);
+					free(up);
 				}
 				n_ins = 0;
 				num_support = -1;
@@ -1486,6 +1780,9 @@ writeEditsToFile(FILE* fa, FILE* tsv, const char* hdr, ctx_t* c)
 						fprintf(tsv, "\t%c\t%u", s->altbase3, s->altsupp3);
 					}
 					fputc('\n', tsv);
+				}
+				if (vcf) {
+					vcf_substitution(vcf, c->annot, hdr, p, s);
 				}
 				q->head++;
 			}
@@ -1511,6 +1808,22 @@ writeEditsToFile(FILE* fa, FILE* tsv, const char* hdr, ctx_t* c)
 					fwrite(seq + pos, 1, curr.s_pos - pos, tsv);
 					fprintf(tsv, "\t%u\n", curr.num_support);
 				}
+				if (vcf && pos > 0) {
+					/* ntedit.cpp:1184-1208 */
+					size_t dl = (size_t)(curr.s_pos - pos) + 1;
+					size_t idcap = strlen(hdr) + dl + 64;
+					char* id = (char*)malloc(idcap);
+					char* up = (char*)malloc(dl + 1);
+					upper_into(up, seq + pos - 1, dl);
+					snprintf(id, idcap, "%s>%s%u%c", hdr, up, pos, (char)toupper((unsigned char)seq[pos - 1]));
+					fprintf(vcf, "%s\t%u\t.\t", hdr, pos);
+					fwrite(seq + pos - 1, 1, dl, vcf);
+					fprintf(vcf, "\t%c\t.\tPASS\tAD=%u", seq[pos - 1], curr.num_support);
+					vcf_annot(vcf, c->annot, id);
+					fprintf(vcf, "\tGT\t1/1\n");
+					free(id);
+					free(up);
+				}
 			}
 		}
 	}
@@ -1534,7 +1847,6 @@ ora_write_tsv_header(FILE* tsv, const ora_params* p, const ora_bf* bloom)
 	fprintf(tsv, "\tAlt.Base1\tAlt.%s1\tAlt.Base2\tAlt.%s2\tAlt.Base3\tAlt.%s3\n", alt, alt, alt);
 }
 
-/* ntedit.cpp:1747-2151 */
 void
 ora_polish_contig(
     const char* hdr,
@@ -1546,9 +1858,28 @@ ora_polish_contig(
     FILE* fa,
     FILE* tsv)
 {
+	ora_polish_contig_vcf(hdr, seq, len, p, bloom, bloomrep, fa, tsv, NULL, NULL);
+}
+
+/* ntedit.cpp:1747-2151 */
+void
+ora_polish_contig_vcf(
+    const char* hdr,
+    char* seq,
+    unsigned len,
+    const ora_params* p,
+    const ora_bf* bloom,
+    const ora_bf* bloomrep,
+    FILE* fa,
+    FILE* tsv,
+    FILE* vcf,
+    const ora_annot* annot)
+{
 	ctx_t cx;
 	ctx_t* c = &cx;
 	memset(c, 0, sizeof(*c));
+	c->vcf = vcf;
+	c->annot = annot;
 	c->p = p;
 	c->bloom = bloom;
 	c->bloomrep = bloomrep;
@@ -1868,6 +2199,19 @@ gz_getline(gzFile f, char** buf, size_t* cap)
 	}
 }
 
+void
+ora_write_vcf_header(FILE* vcf, const char* draft_path)
+{
+	/* ntedit.cpp:2192-2211 */
+	time_t now = time(NULL);
+	struct tm* ltm = localtime(&now);
+	fprintf(vcf, "##fileformat=VCFv4.2\n##fileDate=%04d%02d%02d\n##source=ntEdit v2.1.1\n##reference=file:%s\n",
+	        1900 + ltm->tm_year, 1 + ltm->tm_mon, ltm->tm_mday, draft_path);
+	fprintf(vcf, "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n");
+	fprintf(vcf, "##INFO=<ID=AD,Number=2,Type=Integer,Description=\"Kmer Depth\">\n");
+	fprintf(vcf, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tINTEGRATION\n");
+}
+
 int
 ora_polish_file(
     const char* draft_path,
@@ -1876,6 +2220,19 @@ ora_polish_file(
     const ora_bf* bloomrep,
     const char* prefix,
     uint64_t* bases_out)
+{
+	return ora_polish_file_vcf(draft_path, p, bloom, bloomrep, prefix, bases_out, NULL);
+}
+
+int
+ora_polish_file_vcf(
+    const char* draft_path,
+    const ora_params* p,
+    const ora_bf* bloom,
+    const ora_bf* bloomrep,
+    const char* prefix,
+    uint64_t* bases_out,
+    const ora_annot* annot)
 {
 	gzFile f = gzopen(draft_path, "r");
 	if (!f) {
@@ -1886,10 +2243,13 @@ ora_polish_file(
 	FILE* fa = fopen(path, "w");
 	snprintf(path, sizeof path, "%s_changes.tsv", prefix);
 	FILE* tsv = fopen(path, "w");
-	if (!fa || !tsv) {
+	snprintf(path, sizeof path, "%s_variants.vcf", prefix);
+	FILE* vcf = fopen(path, "w");
+	if (!fa || !tsv || !vcf) {
 		return -2;
 	}
 	ora_write_tsv_header(tsv, p, bloom);
+	ora_write_vcf_header(vcf, draft_path);
 
 	char* line = NULL;
 	size_t cap = 0;
@@ -1909,7 +2269,7 @@ ora_polish_file(
 						seq = (char*)calloc(1, 1);
 					}
 					seq[seq_len] = 0;
-					ora_polish_contig(hdr, seq, (unsigned)seq_len, p, bloom, bloomrep, fa, tsv);
+					ora_polish_contig_vcf(hdr, seq, (unsigned)seq_len, p, bloom, bloomrep, fa, tsv, vcf, annot);
 					bases += seq_len;
 				}
 			}
@@ -1970,6 +2330,7 @@ ora_polish_file(
 	gzclose(f);
 	fclose(fa);
 	fclose(tsv);
+	fclose(vcf);
 	if (bases_out) {
 		*bases_out = bases;
 	}

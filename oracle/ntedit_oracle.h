@@ -98,6 +98,32 @@ void ora_polish_contig(
 
 void ora_write_tsv_header(FILE* tsv, const ora_params* p, const ora_bf* bloom);
 
+/* -l annotation map (ntedit.cpp:2261-2274,2524-2562) and the _variants.vcf writer
+ * (ntedit.cpp:951-977,986-1162,1184-1208; header 2192-2211) */
+typedef struct ora_annot ora_annot;
+ora_annot* ora_annot_load(const char* path);
+void ora_annot_free(ora_annot* m);
+void ora_write_vcf_header(FILE* vcf, const char* draft_path);
+void ora_polish_contig_vcf(
+    const char* hdr,
+    char* seq,
+    unsigned len,
+    const ora_params* p,
+    const ora_bf* bloom,
+    const ora_bf* bloomrep,
+    FILE* fa,
+    FILE* tsv,
+    FILE* vcf,
+    const ora_annot* annot);
+int ora_polish_file_vcf(
+    const char* draft_path,
+    const ora_params* p,
+    const ora_bf* bloom,
+    const ora_bf* bloomrep,
+    const char* prefix,
+    uint64_t* bases_out,
+    const ora_annot* annot);
+
 /* whole-file driver = readAndCorrect at -t 1 (ntedit.cpp:2154-2259) */
 int ora_polish_file(
     const char* draft_path,

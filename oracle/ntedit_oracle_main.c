@@ -25,7 +25,7 @@ main(int argc, char** argv)
 {
 	ora_params p;
 	ora_params_default(&p);
-	const char *draft = NULL, *bfpath = NULL, *bfrep = NULL, *prefix = NULL;
+	const char *draft = NULL, *bfpath = NULL, *bfrep = NULL, *prefix = NULL, *annot_path = NULL;
 	int report = 0;
 	static const struct option longopts[] = { { "report", no_argument, NULL, 1000 },
 		                                      { NULL, 0, NULL, 0 } };
@@ -87,10 +87,12 @@ main(int argc, char** argv)
 		case 1000:
 			report = 1;
 			break;
+		case 'l':
+			annot_path = optarg;
+			break;
 		case 't':
 		case 'k':
 		case 'c':
-		case 'l':
 		case 'v':
 			break; /* accepted, no effect on this path */
 		default:
@@ -138,7 +140,9 @@ main(int argc, char** argv)
 	uint64_t bases = 0;
 	struct timespec t0, t1;
 	clock_gettime(CLOCK_MONOTONIC, &t0);
-	int rc = ora_polish_file(draft, &p, &bloom, bfrep ? &bloomrep : NULL, prefix, &bases);
+	ora_annot* annot = annot_path ? ora_annot_load(annot_path) : NULL;
+	int rc = ora_polish_file_vcf(draft, &p, &bloom, bfrep ? &bloomrep : NULL, prefix, &bases, annot);
+	ora_annot_free(annot);
 	clock_gettime(CLOCK_MONOTONIC, &t1);
 	if (report) {
 		double s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);

@@ -24,6 +24,7 @@ CASES = {
                                dict(mode=1, mask=1, max_deletions=8)),
     "secondary_ratio": (dict(n=12000, contigs=2, flavor="sec iupac", bfbytes=1 << 14), dict(use_ratio=1, jump=2)),
     "counting_p2": (dict(n=12000, contigs=2, flavor="cbf", bfbytes=1 << 13), dict(min_threshold=2, max_threshold=5)),
+    "snv_mode": (dict(n=6000, contigs=2, flavor="iupac", bfbytes=1 << 13), dict(snv=1)),
 }
 
 
@@ -43,6 +44,10 @@ def main():
         hp = H.default_params(**pkw)
         H.run_oracle(os.path.join(d, "draft.fa"), os.path.join(d, "filter.bf"), hp, os.path.join(d, "expected"),
                      os.path.join(d, "secondary.bf") if case["rep"] else None)
+        # the VCF minus its date / input-path header lines
+        with open(os.path.join(d, "expected_variants.vcf.body"), "w") as f:
+            f.write("\n".join(H.vcf_body(os.path.join(d, "expected_variants.vcf"))) + "\n")
+        os.remove(os.path.join(d, "expected_variants.vcf"))
         with open(os.path.join(d, "params.txt"), "w") as f:
             f.write(" ".join(H.oracle_args(hp)) + "\n")
         print(name, sum(1 for _ in open(os.path.join(d, "expected_changes.tsv"))) - 1, "rows")

@@ -164,7 +164,13 @@ def pack_batch(recs, min_len=0):
     return blob, np.array(offs, dtype=np.uint64), np.array(lens, dtype=np.uint32), names
 
 
-def run_hostsim(recs, bf, params, out_prefix, rep=None):
+def vcf_body(path):
+    """VCF lines without the two header lines that depend on the day / the input path"""
+    return [l for l in open(path).read().splitlines()
+            if not l.startswith("##fileDate=") and not l.startswith("##reference=")]
+
+
+def run_hostsim(recs, bf, params, out_prefix, rep=None, annot_path=None):
     lib = hostsim_lib()
     blob, offs, lens, names = pack_batch(recs, params.min_contig_len)
     n = len(names)
@@ -183,7 +189,8 @@ def run_hostsim(recs, bf, params, out_prefix, rep=None):
         ctypes.byref(params),
         (out_prefix + "_edited.fa").encode(), (out_prefix + "_changes.tsv").encode(),
         ctypes.byref(nev), ctypes.byref(nap),
-        ctypes.c_int(1 if bf.get("counting") else 0), ctypes.c_int(1 if (rep and rep.get("counting")) else 0))
+        ctypes.c_int(1 if bf.get("counting") else 0), ctypes.c_int(1 if (rep and rep.get("counting")) else 0),
+        (out_prefix + "_variants.vcf").encode(), annot_path.encode() if annot_path else None)
     return rc, nev.value, nap.value
 
 
@@ -198,11 +205,13 @@ def oracle_args(params):
     return a
 
 
-def run_oracle(draft_path, bf_path, params, out_prefix, rep_path=None):
+def run_oracle(draft_path, bf_path, params, out_prefix, rep_path=None, annot_path=None):
     build_oracle()
     cmd = [os.path.join(ORACLE_BUILD, "ntedit_oracle"), "-f", draft_path, "-r", bf_path, "-b", out_prefix]
     if rep_path:
         cmd += ["-e", rep_path]
+    if annot_path:
+        cmd += ["-l", annot_path]
     cmd += oracle_args(params)
     subprocess.run(cmd, check=True)
 

@@ -100,7 +100,9 @@ hostsim_polish(
     uint64_t* n_events_out,
     uint64_t* n_applied_out,
     int counting,
-    int rep_counting)
+    int rep_counting,
+    const char* vcf_path,
+    const char* annot_path)
 {
 	DevParams p;
 	int rc = nte_host::make_dev_params(*hp, k, hash_num, rep != nullptr, &p, counting != 0);
@@ -209,6 +211,14 @@ hostsim_polish(
 	if (tsv) {
 		nte_host::write_tsv_header(tsv, k, hp->jump, counting != 0);
 	}
+	FILE* vcf = vcf_path ? fopen(vcf_path, "w") : nullptr;
+	if (vcf) {
+		nte_host::write_vcf_header(vcf, "draft");
+	}
+	nte_host::RenderOptions ropt;
+	ropt.snv = hp->snv != 0;
+	nte_host::Annotations* ann = annot_path ? nte_host::annotations_load(annot_path) : nullptr;
+	ropt.annot = ann;
 	nte_host::RenderStats st;
 	rc = nte_host::render_batch(
 	    arena.data(),
@@ -222,7 +232,13 @@ hostsim_polish(
 	    n_contigs,
 	    fa,
 	    tsv,
-	    &st);
+	    &st,
+	    vcf,
+	    &ropt);
+	if (vcf) {
+		fclose(vcf);
+	}
+	nte_host::annotations_free(ann);
 	if (fa) {
 		fclose(fa);
 	}

@@ -40,4 +40,5 @@ def test_two_rank_gloo_run_matches_oracle(tmp_path, oracle_build):
     assert r.returncode == 0, r.stderr[-2000:]
     assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "d_edited.fa"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "d_changes.tsv"), shallow=False)
+    assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "d_variants.vcf"))
     assert not [f for f in os.listdir(str(tmp_path)) if ".shard" in f]

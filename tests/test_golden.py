@@ -17,7 +17,8 @@ def params_from_file(path):
     kw = {}
     key = {"-z": ("min_contig_len", int), "-i": ("max_insertions", int), "-d": ("max_deletions", int),
            "-j": ("jump", int), "-m": ("mode", int), "-a": ("mask", int), "-p": ("min_threshold", int),
-           "-q": ("max_threshold", int), "-x": ("missing_threshold", float), "-y": ("edit_threshold", float),
+           "-q": ("max_threshold", int), "-s": ("snv", int), "-x": ("missing_threshold", float),
+           "-y": ("edit_threshold", float),
            "-X": ("missing_ratio", float), "-Y": ("edit_ratio", float)}
     for flag, val in zip(toks[0::2], toks[1::2]):
         name, conv = key[flag]
@@ -36,6 +37,8 @@ def test_oracle_reproduces_golden(tmp_path, name, oracle_build):
                  rep if os.path.exists(rep) else None)
     assert filecmp.cmp(os.path.join(d, "expected_changes.tsv"), str(tmp_path / "o_changes.tsv"), shallow=False)
     assert filecmp.cmp(os.path.join(d, "expected_edited.fa"), str(tmp_path / "o_edited.fa"), shallow=False)
+    assert open(os.path.join(d, "expected_variants.vcf.body")).read().splitlines() == \
+        H.vcf_body(str(tmp_path / "o_variants.vcf"))
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -48,3 +51,5 @@ def test_hostsim_reproduces_golden(tmp_path, name, oracle_build):
     assert rc == 0
     assert filecmp.cmp(os.path.join(d, "expected_changes.tsv"), str(tmp_path / "h_changes.tsv"), shallow=False)
     assert filecmp.cmp(os.path.join(d, "expected_edited.fa"), str(tmp_path / "h_edited.fa"), shallow=False)
+    assert open(os.path.join(d, "expected_variants.vcf.body")).read().splitlines() == \
+        H.vcf_body(str(tmp_path / "h_variants.vcf"))

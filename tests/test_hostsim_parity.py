@@ -32,6 +32,8 @@ def test_hostsim_matches_oracle(tmp_path, ci, two_pass, oracle_build, monkeypatc
     assert rc == 0
     assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "h_changes.tsv"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "h_edited.fa"), shallow=False)
+    # _variants.vcf: everything but the date / input-path header lines
+    assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))
     assert nev >= nap > 0
 
 
@@ -54,3 +56,32 @@ def test_partition_independence(tmp_path, oracle_build):
     a = sorted(outs[0].splitlines()[1:])
     b = sorted(open(str(tmp_path / "rev_changes.tsv")).read().splitlines()[1:])
     assert a == b
+
+
+def test_vcf_annotations(tmp_path, oracle_build):
+    """-l: variants found in the annotation VCF get its INFO field appended, others ^NA;
+    plain and gzipped annotation files; SNV and polish mode"""
+    import gzip
+    for snv in (0, 1):
+        case = H.make_case(str(tmp_path / ("c%d" % snv)), 4242 + snv, n=8000, contigs=2, p_sub=5e-3, p_ins=1e-3, p_del=1e-3)
+        hp = H.default_params(snv=snv)
+        H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "pre"))
+        rows = [l.split("\t") for l in H.vcf_body(str(tmp_path / "pre_variants.vcf")) if not l.startswith("#")]
+        assert rows
+        # annotate every second variant: CHROM POS ID REF ALT QUAL FILTER INFO
+        ann = str(tmp_path / ("ann%d.vcf" % snv))
+        with open(ann, "w") as f:
+            f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+            for i, r in enumerate(rows):
+                if i % 2 == 0:
+                    alt = r[4].split(",")[0]
+                    f.write("%s\t%s\trs%d\t%s\t%s\t.\t.\tCLNSIG=test%d;X=1\n" % (r[0], r[1], i, r[3].upper(), alt.upper(), i))
+        with open(ann, "rb") as fi, gzip.open(ann + ".gz", "wb") as fo:
+            fo.write(fi.read())
+        for a in (ann, ann + ".gz"):
+            H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), annot_path=a)
+            rc, _, _ = H.run_hostsim(H.read_fasta(case["draft"]), H.load_bf(case["bf"]), hp, str(tmp_path / "h"), annot_path=a)
+            assert rc == 0
+            ob = H.vcf_body(str(tmp_path / "o_variants.vcf"))
+            assert ob == H.vcf_body(str(tmp_path / "h_variants.vcf"))
+            assert any("CLNSIG=test" in l for l in ob) and any("^NA" in l for l in ob)

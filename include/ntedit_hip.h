@@ -31,7 +31,7 @@ extern "C" {
 #define NTEDIT_E_NOFILTER (-3) /* primary Bloom filter not set             */
 #define NTEDIT_E_OVERFLOW (-4) /* internal capacity exceeded after retries */
 #define NTEDIT_E_IO (-5)       /* file could not be read / written         */
-#define NTEDIT_E_UNSUPPORTED (-6) /* SNV mode (-s 1): not on this path yet */
+#define NTEDIT_E_UNSUPPORTED (-6) /* operation not available (e.g. GPU build of a counting filter) */
 
 #define NTEDIT_FILTER_PRIMARY 0   /* -r  (ntedit.cpp:2438) */
 #define NTEDIT_FILTER_SECONDARY 1 /* -e  (ntedit.cpp:2570) */
@@ -53,7 +53,7 @@ typedef struct ntedit_hip_params
 	int32_t use_ratio;         /* set when -X or -Y was given */
 	uint32_t jump;             /* -j */
 	int32_t mode;              /* -m */
-	int32_t snv;               /* -s (unsupported on this path: NTEDIT_E_UNSUPPORTED) */
+	int32_t snv;               /* -s */
 	int32_t mask;              /* -a */
 	uint32_t min_threshold;    /* -p (counting filters only; forced to 1 for plain filters) */
 	uint32_t max_threshold;    /* -q (counting filters only) */

@@ -1200,7 +1200,7 @@ ntedit_hip_polish_batch(
 			HIP_TRY(c, hipMemsetAsync(d_ndef, 0, 4, sB));
 			HIP_TRY(c, hipEventRecord(c->ev[3], sB));
 			// pass 1: every event, indel sweeps postponed
-			hipLaunchKernelGGL(k_machine<false>, dim3((unsigned)blocks), dim3(MACHINE_TPB), dyn_lds, sB, a);
+			launch_k_machine_thread((unsigned)blocks, dyn_lds, sB, a);
 			HIP_TRY(c, hipGetLastError());
 			u32 h_tail[4] = { 0, 0, 0, 0 };
 			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
@@ -1218,7 +1218,7 @@ ntedit_hip_polish_batch(
 				const u64 cap2 = (u64)c->cu_count * 8;
 				const u64 b2 = want2 < cap2 ? want2 : cap2;
 				const size_t dyn2 = a.win_in_lds ? (size_t)a.win_bytes * 4 : 0;
-				hipLaunchKernelGGL(k_machine<true>, dim3((unsigned)b2), dim3(MACHINE_TPB), dyn2, sB, a);
+				launch_k_machine_wave((unsigned)b2, dyn2, sB, a);
 				HIP_TRY(c, hipGetLastError());
 			}
 			HIP_TRY(c, hipEventRecord(c->ev[4], sB));

@@ -13,6 +13,7 @@
 // Roofline: all of this is integer hashing + random 1-byte gathers from a
 // multi-GiB bit array => HBM random-read bound; no MFMA anywhere.
 #include "nte_machine.h"
+#include "nte_machine_launch.h"
 
 #include <hip/hip_runtime.h>
 
@@ -646,134 +647,9 @@ k_write_starts(
 	}
 }
 
-// ----------------------------------------------------------------- k_machine
-struct MachineArgs
-{
-	const u8* seq;
-	u64 n_bytes;        // batch bytes
-	const u64* offsets; // start of every contig in the batch
-	const u32* lens;
-	u32 n_contigs;
-	const u64* bitmap;
-	const u64* events;
-	u64 n_events;
-	const u64* tabs;
-	DevParams p;
-	Filter bloom, rep;
-	// per-thread workspace slabs
-	Node* ws_nodes;
-	u32* ws_ov_pos;
-	u8* ws_ov_chr;
-	u8* ws_prev;
-	int16_t* ws_lps;
-	u8* ws_win;     // used when the windows do not fit in LDS
-	u32 win_bytes;  // window bytes per thread
-	u32 win_in_lds;
-	// output
-	Item* arena;
-	u32* arena_next;
-	u32 arena_chunks;
-	u32* first_chunk; // per event
-	u32* status;      // OR of EV_OVERFLOW / EV_ARENA_FULL seen
-	// two-pass launch: pass 1 (defer = 1) postpones events that need an indel sweep by
-	// appending their index to `deferred`; pass 2 runs exactly that list (ev_list)
-	u32 defer;
-	const u32* ev_list; // nullptr = all events 0..n_events-1
-	u32* deferred;
-	u32* n_deferred;
-};
-
-constexpr int MACHINE_TPB = 256;
-
-// WAVE = false: one thread per event (pass 1 / single pass).
-// WAVE = true : one wavefront per event (the sweep-only second pass): all 64 lanes run the
-//               same serial machine on one shared workspace and split the candidate sweep.
-template<bool WAVE>
-__global__ __launch_bounds__(MACHINE_TPB, 4) void
-k_machine(MachineArgs a)
-{
-	__shared__ u64 s_tab[TAB_WORDS];
-	extern __shared__ __attribute__((aligned(16))) u8 s_win[];
-	if (threadIdx.x < TAB_WORDS) {
-		s_tab[threadIdx.x] = a.tabs[threadIdx.x];
-	}
-	__syncthreads();
-	const u64 gtid = (u64)blockIdx.x * MACHINE_TPB + threadIdx.x;
-	// "worker" = the unit that owns one event at a time: a thread or a wave
-	const u64 worker = WAVE ? (gtid >> 6) : gtid;
-	const u64 nworkers = WAVE ? ((u64)gridDim.x * MACHINE_TPB) >> 6 : (u64)gridDim.x * MACHINE_TPB;
-	const u64 W = a.p.node_window;
-
-	EventEnv env;
-	env.bitmap = a.bitmap;
-	env.tab = s_tab;
-	env.p = &a.p;
-	env.bloom = a.bloom;
-	env.rep = a.rep;
-	env.nodes = a.ws_nodes + worker * W;
-	env.ov_pos = a.ws_ov_pos + worker * W;
-	env.ov_chr = a.ws_ov_chr + worker * W;
-	if (a.win_in_lds) {
-		if (WAVE) {
-			env.win = s_win + (threadIdx.x >> 6) * a.win_bytes;
-			env.win_stride = 1;
-		} else {
-			// interleaved: byte i of thread t at s_win[i * 256 + t] (no bank conflicts when
-			// the lanes of a wave read the same i)
-			env.win = s_win + threadIdx.x;
-			env.win_stride = MACHINE_TPB;
-		}
-	} else {
-		env.win = a.ws_win + worker * a.win_bytes;
-		env.win_stride = 1;
-	}
-	env.prev = a.ws_prev + worker * W;
-	env.lps = a.ws_lps + worker * W;
-	env.arena = a.arena;
-	env.arena_next = a.arena_next;
-	env.arena_chunks = a.arena_chunks;
-	env.defer_sweeps = a.defer != 0;
-	env.wave_size = WAVE ? 64 : 1;
-	const bool leader = !WAVE || (threadIdx.x & 63) == 0;
-
-	for (u64 it = worker; it < a.n_events; it += nworkers) {
-		const u64 ev = a.ev_list ? a.ev_list[it] : it;
-		const u64 g = a.events[ev];
-		// contig of g: last offset <= g
-		u32 lo = 0, hi = a.n_contigs;
-		while (hi - lo > 1) {
-			const u32 mid = lo + ((hi - lo) >> 1);
-			if (a.offsets[mid] <= g) {
-				lo = mid;
-			} else {
-				hi = mid;
-			}
-		}
-		env.contig = lo;
-		env.gbase = a.offsets[lo];
-		env.seq = a.seq + env.gbase;
-		env.batch_end = a.seq + a.n_bytes;
-		env.len = a.lens[lo];
-		const u32 start = (u32)(g - env.gbase);
-		u32 fc = NONE32;
-		if ((u64)start + a.p.k <= env.len) {
-			Machine m(env);
-			u32 cover_end = start;
-			m.run(start, cover_end);
-			fc = m.finish(start, cover_end);
-			if (leader) {
-				if (m.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
-					atomicOr(a.status, m.flags & (EV_OVERFLOW | EV_ARENA_FULL));
-				} else if (m.flags & EV_DEFERRED) {
-					a.deferred[atomicAdd(a.n_deferred, 1u)] = (u32)ev;
-				}
-			}
-		}
-		if (leader) {
-			a.first_chunk[ev] = fc;
-		}
-	}
-}
+// (k_machine lives in its own translation units, nte_machine_thread.hip / nte_machine_wave.hip:
+// the fully inlined state machine is by far the largest kernel and the two variants compile in
+// parallel; interface in nte_machine_launch.h)
 
 // ------------------------------------------------------------------ k_gather
 // Uniform random 1-byte gathers, 12 independent loads in flight per lane

@@ -1,0 +1,52 @@
+// nte_machine_launch.h -- launch interface of the event-machine kernels.
+#pragma once
+#include "nte_machine.h"
+
+#include <hip/hip_runtime.h>
+
+namespace nte {
+
+struct MachineArgs
+{
+	const u8* seq;
+	u64 n_bytes;        // batch bytes
+	const u64* offsets; // start of every contig in the batch
+	const u32* lens;
+	u32 n_contigs;
+	const u64* bitmap;
+	const u64* events;
+	u64 n_events;
+	const u64* tabs;
+	DevParams p;
+	Filter bloom, rep;
+	// per-thread workspace slabs
+	Node* ws_nodes;
+	u32* ws_ov_pos;
+	u8* ws_ov_chr;
+	u8* ws_prev;
+	int16_t* ws_lps;
+	u8* ws_win;     // used when the windows do not fit in LDS
+	u32 win_bytes;  // window bytes per thread
+	u32 win_in_lds;
+	// output
+	Item* arena;
+	u32* arena_next;
+	u32 arena_chunks;
+	u32* first_chunk; // per event
+	u32* status;      // OR of EV_OVERFLOW / EV_ARENA_FULL seen
+	// two-pass launch: pass 1 (defer = 1) postpones events that need an indel sweep by
+	// appending their index to `deferred`; pass 2 runs exactly that list (ev_list)
+	u32 defer;
+	const u32* ev_list; // nullptr = all events 0..n_events-1
+	u32* deferred;
+	u32* n_deferred;
+};
+
+constexpr int MACHINE_TPB = 256;
+
+// one thread per event (pass 1 / single pass)
+void launch_k_machine_thread(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);
+// one wavefront per event (sweep-only second pass)
+void launch_k_machine_wave(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);
+
+} // namespace nte

@@ -1,0 +1,12 @@
+// k_machine<false>: one thread per event.
+#include "nte_machine_kernel.inc"
+
+namespace nte {
+
+void
+launch_k_machine_thread(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a)
+{
+	hipLaunchKernelGGL(k_machine<false>, dim3(blocks), dim3(MACHINE_TPB), dyn_lds, stream, a);
+}
+
+} // namespace nte

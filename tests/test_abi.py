@@ -16,7 +16,7 @@ LIB = os.path.join(H.ROOT, "ntedit_amd", "libntedit_hip.so")
 @pytest.fixture(scope="module")
 def built_lib():
     if not os.path.exists(LIB):
-        subprocess.run(["make", "-s", "-C", os.path.join(H.ROOT, "ntedit_amd", "csrc")], check=True)
+        subprocess.run(["make", "-s", "-j4", "-C", os.path.join(H.ROOT, "ntedit_amd", "csrc")], check=True)
     return LIB
 
 

@@ -408,6 +408,35 @@ launch_bin(ntedit_hip_ctx* c, hipStream_t stream, const BinArgs& a, u64 blocks)
 #undef NTE_BIN
 }
 
+template<int H, bool POW2>
+int
+launch_bin_sort_t(ntedit_hip_ctx* c, hipStream_t stream, const BinArgs& a, u64 blocks)
+{
+	static bool attr_set = false;
+	if (!attr_set) {
+		HIP_TRY(c, hipFuncSetAttribute(
+		               reinterpret_cast<const void*>(&k_bin_sort<H, POW2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		               (int)SORT_LDS_BYTES));
+		attr_set = true;
+	}
+	hipLaunchKernelGGL((k_bin_sort<H, POW2>), dim3((unsigned)blocks), dim3(SORT_TPB), SORT_LDS_BYTES, stream, a);
+	return 0;
+}
+
+int
+launch_bin_sort(ntedit_hip_ctx* c, hipStream_t stream, const BinArgs& a, u64 blocks)
+{
+	const bool pow2 = a.f.mask != 0;
+	switch (a.f.hash_num) {
+	case 1:
+		return pow2 ? launch_bin_sort_t<1, true>(c, stream, a, blocks) : launch_bin_sort_t<1, false>(c, stream, a, blocks);
+	case 2:
+		return pow2 ? launch_bin_sort_t<2, true>(c, stream, a, blocks) : launch_bin_sort_t<2, false>(c, stream, a, blocks);
+	default:
+		return pow2 ? launch_bin_sort_t<3, true>(c, stream, a, blocks) : launch_bin_sort_t<3, false>(c, stream, a, blocks);
+	}
+}
+
 int
 run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words, u32 slog, u32 n_slices, hipStream_t stream, u64 pos_begin, u64 pos_end)
 {
@@ -464,7 +493,19 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		hipLaunchKernelGGL(
 		    k_bin_scan, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)c->bin_totals.p, n_slices,
 		    (unsigned long long*)c->bin_bases.p, (unsigned long long*)c->bin_totals.p);
-		launch_bin<BIN_WRITE>(c, stream, a, blocks);
+		if (f.hash_num <= SORT_MAX_H && getenv("NTEDIT_HIP_BIN_SORT")) {
+			// LDS-sorted write stage (full-line stores).  Measured: 56 ms per Gbp vs 38 ms for
+			// the plain scatter -- a 4096-k-mer tile is all the LDS holds, and its 2048 run
+			// reservations per tile (global atomics) plus four waves per CU cost more than the
+			// coalescing wins.  Kept for experiments only.
+			const u64 sblocks = (end - begin + SORT_TILE - 1) / SORT_TILE;
+			rc = launch_bin_sort(c, stream, a, sblocks);
+			if (rc) {
+				return rc;
+			}
+		} else {
+			launch_bin<BIN_WRITE>(c, stream, a, blocks);
+		}
 		hipLaunchKernelGGL(
 		    k_bin_probe, dim3(c->cu_count * 8), dim3(PROBE_TPB), 0, stream, f.data, (const u64*)c->bin_records.p,
 		    (const unsigned long long*)c->bin_bases.p, n_slices, slog, (u32*)c->bin_work.p, (u32*)d_bitmap);

@@ -376,6 +376,174 @@ k_bin(BinArgs a)
 	}
 }
 
+// k_bin_sort: the WRITE stage with full-line stores.  k_bin<WRITE> scatters every 8-byte
+// record on its own (one partial-line store per probe, ~80 G stores/s).  Here a workgroup
+// sorts the records of its tile by slice in LDS first (counting sort with LDS atomics), then
+// copies the sorted array out linearly: consecutive lanes hold consecutive records of the same
+// (tile, slice) run, i.e. consecutive global addresses, so the stores coalesce into lines.
+constexpr int SORT_TPB = 256;
+constexpr int SORT_L = 16; // k-mer starts per thread
+constexpr int SORT_TILE = SORT_TPB * SORT_L;
+constexpr int SORT_MAX_H = 3;
+constexpr int SORT_CODE_BYTES = ((SORT_TILE + SCREEN_MAXK + 63) / 64) * 68 + 16;
+// dynamic LDS: records | cnt | loff | gbase | codes
+constexpr size_t SORT_LDS_BYTES = (size_t)SORT_TILE * SORT_MAX_H * 8 + (size_t)BIN_MAX_SLICES * 4 * 2 +
+                                  (size_t)(BIN_MAX_SLICES + 1) * 4 + SORT_CODE_BYTES;
+
+template<int H, bool POW2>
+__global__ __launch_bounds__(SORT_TPB) void
+k_bin_sort(BinArgs a)
+{
+	__shared__ u64 s_tab[TAB_WORDS];
+	__shared__ u8 s_lut[256];
+	__shared__ u32 s_scan[SORT_TPB];
+	extern __shared__ __attribute__((aligned(16))) u8 s_dyn[];
+	u64* s_rec = reinterpret_cast<u64*>(s_dyn);
+	u32* s_cnt = reinterpret_cast<u32*>(s_dyn + (size_t)SORT_TILE * SORT_MAX_H * 8);
+	u32* s_gbase = s_cnt + BIN_MAX_SLICES;
+	u32* s_loff = s_gbase + BIN_MAX_SLICES; // n_slices + 1 entries
+	u8* s_codes = reinterpret_cast<u8*>(s_loff + BIN_MAX_SLICES + 1);
+
+	const u32 tid = threadIdx.x;
+	if (tid < TAB_WORDS) {
+		s_tab[tid] = a.tabs[tid];
+	}
+	s_lut[tid] = char_code((u8)tid);
+	for (u32 b = tid; b < a.n_slices; b += SORT_TPB) {
+		s_cnt[b] = 0;
+	}
+	__syncthreads();
+
+	const u64 tile_base = a.chunk_begin + (u64)blockIdx.x * SORT_TILE;
+	const u32 k = a.p.k;
+	const u32 n_chunks = (SORT_TILE + k - 1 + 15) / 16;
+	for (u32 c = tid; c < n_chunks; c += SORT_TPB) {
+		const u64 g = tile_base + (u64)c * 16;
+		u32 w[4];
+		if (g + 16 <= a.n) {
+			const uint4 v = *reinterpret_cast<const uint4*>(a.seq + g);
+			w[0] = v.x;
+			w[1] = v.y;
+			w[2] = v.z;
+			w[3] = v.w;
+		} else {
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				u32 x = 0;
+#pragma unroll
+				for (int b = 0; b < 4; b++) {
+					const u64 gg = g + q * 4 + b;
+					const u32 ch = gg < a.n ? a.seq[gg] : (u32)'\n';
+					x |= ch << (8 * b);
+				}
+				w[q] = x;
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const u32 x = w[q];
+			const u32 codes = (u32)s_lut[x & 0xFF] | ((u32)s_lut[(x >> 8) & 0xFF] << 8) |
+			                  ((u32)s_lut[(x >> 16) & 0xFF] << 16) | ((u32)s_lut[x >> 24] << 24);
+			*reinterpret_cast<u32*>(&s_codes[lds_phys(c * 16 + q * 4)]) = codes;
+		}
+	}
+	__syncthreads();
+
+	const u32 x0 = tid * SORT_L;
+	const u32 ksh = (k & 3) * 8;
+	const u32 slog = a.slice_log2;
+	const u64 slice_mask = (1ULL << slog) - 1;
+
+	auto pass = [&](bool place) {
+		HashState hs = { 0, 0 };
+		u32 good = 0;
+		for (u32 i = 0; i < k; i++) {
+			const u8 in = s_codes[lds_phys(x0 + i)];
+			hash_roll(hs, s_tab, CODE_BAD, in);
+			good = in == CODE_BAD ? 0 : good + 1;
+		}
+		u32 in_lo = *reinterpret_cast<const u32*>(&s_codes[lds_phys((x0 + k) & ~3u)]);
+		for (u32 j0 = 0; j0 < SORT_L; j0 += 4) {
+			const u32 outw = *reinterpret_cast<const u32*>(&s_codes[lds_phys(x0 + j0)]);
+			const u32 in_hi = *reinterpret_cast<const u32*>(&s_codes[lds_phys(((x0 + j0 + k) & ~3u) + 4)]);
+			const u32 inw = ksh ? ((in_lo >> ksh) | (in_hi << (32 - ksh))) : in_lo;
+			in_lo = in_hi;
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const u64 pos = tile_base + x0 + j0 + u;
+				if (good >= k && pos < a.chunk_end) {
+					const u64 base = hs.fh + hs.rh;
+#pragma unroll
+					for (int i = 0; i < H; i++) {
+						const u64 hv = hash_extend(base, a.p, i);
+						const u64 slot = POW2 ? (hv & a.f.mask) : (hv % a.f.bits);
+						const u32 sl = (u32)(slot >> slog);
+						const u32 r = atomicAdd(&s_cnt[sl], 1u);
+						if (place) {
+							s_rec[s_loff[sl] + r] = (pos << slog) | (slot & slice_mask);
+						}
+					}
+				}
+				const u8 out = (outw >> (8 * u)) & 0xFF;
+				const u8 in = (inw >> (8 * u)) & 0xFF;
+				hash_roll(hs, s_tab, out, in);
+				good = in == CODE_BAD ? 0 : good + 1;
+			}
+		}
+	};
+
+	pass(false);
+	__syncthreads();
+	// exclusive prefix of the slice counts -> local offsets; reserve the global runs
+	{
+		const u32 per = (a.n_slices + SORT_TPB - 1) / SORT_TPB;
+		const u32 b0 = tid * per;
+		u32 sum = 0;
+		for (u32 b = b0; b < b0 + per && b < a.n_slices; b++) {
+			sum += s_cnt[b];
+		}
+		s_scan[tid] = sum;
+		__syncthreads();
+		for (int off = 1; off < SORT_TPB; off <<= 1) {
+			u32 t = 0;
+			if ((int)tid >= off) {
+				t = s_scan[tid - off];
+			}
+			__syncthreads();
+			s_scan[tid] += t;
+			__syncthreads();
+		}
+		u32 run = s_scan[tid] - sum;
+		for (u32 b = b0; b < b0 + per && b < a.n_slices; b++) {
+			const u32 cnt = s_cnt[b];
+			s_loff[b] = run;
+			run += cnt;
+			s_gbase[b] = cnt ? (u32)atomicAdd(&a.totals[b], (unsigned long long)cnt) : 0;
+			s_cnt[b] = 0;
+		}
+		if (tid == SORT_TPB - 1) {
+			s_loff[a.n_slices] = s_scan[SORT_TPB - 1];
+		}
+	}
+	__syncthreads();
+	pass(true);
+	__syncthreads();
+	// linear copy-out; the slice of sorted record i = last b with loff[b] <= i
+	const u32 n_rec = s_loff[a.n_slices];
+	for (u32 i = tid; i < n_rec; i += SORT_TPB) {
+		u32 lo = 0, hi = a.n_slices;
+		while (hi - lo > 1) {
+			const u32 mid = (lo + hi) >> 1;
+			if (s_loff[mid] <= i) {
+				lo = mid;
+			} else {
+				hi = mid;
+			}
+		}
+		a.records[(u64)s_gbase[lo] + (i - s_loff[lo])] = s_rec[i];
+	}
+}
+
 // exclusive scan of the slice totals (single workgroup); cursors[b] = bases[b]
 __global__ __launch_bounds__(1024) void
 k_bin_scan(const unsigned long long* totals, u32 n_slices, unsigned long long* bases, unsigned long long* cursors)

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libntedit_hip.so")
+LIB_PATH = os.environ.get("NTEDIT_HIP_LIB") or os.path.join(_HERE, "libntedit_hip.so")  # (override: A/B builds)
 
 
 class NtEditHipError(RuntimeError):

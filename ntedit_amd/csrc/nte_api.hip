@@ -992,7 +992,13 @@ ntedit_hip_polish_batch(
 	if (n == 0 || n_contigs == 0) {
 		return 0;
 	}
+	PinBuf early; // pass-1 edit records copied to the host while pass 2 runs
+	early.p = nullptr;
+	early.cap = 0;
+	u64 early_chunks = 0;
 	auto bail = [&](int code) {
+		(void)hipDeviceSynchronize(); // an early copy may still be in flight
+		pin_give(c, early);
 		pin_give(c, r->arena_buf);
 		pin_give(c, r->first_buf);
 		delete r;
@@ -1090,6 +1096,8 @@ ntedit_hip_polish_batch(
 		arena_chunks = c->arena.cap / (CHUNK_ITEMS * sizeof(Item));
 	}
 	for (int attempt = 0;; attempt++) {
+		pin_give(c, early); // (streams are idle here)
+		early_chunks = 0;
 		if (arena_chunks > 0xFFFFFFF0ull) {
 			return bail(fail(c, NTEDIT_E_OVERFLOW, "edit-record arena exceeds 2^32 chunks"));
 		}
@@ -1234,6 +1242,8 @@ ntedit_hip_polish_batch(
 			a.arena_chunks = (u32)arena_chunks;
 			a.first_chunk = d_first;
 			a.status = d_status;
+			a.lds_ws_off = 0;
+			a.lds_slab = 0;
 			a.defer = 1;
 			a.ev_list = nullptr;
 			a.deferred = (u32*)c->deferred.p;
@@ -1250,15 +1260,44 @@ ntedit_hip_polish_batch(
 			const u32 n_def = h_tail[3];
 			deferred_total += n_def;
 			status = h_tail[2];
+			if (n_def > 0 && status == 0 && n_ch == 1 && !getenv("NTEDIT_HIP_NO_EARLY_COPY")) {
+				// everything pass 1 wrote is final (pass 2 only appends chunks): start moving it
+				// to the host on the other stream while pass 2 runs
+				early_chunks = h_tail[0] < arena_chunks ? h_tail[0] : arena_chunks;
+				const u64 room = early_chunks + (u64)n_def * 3 + 4096;
+				if ((rc = pin_take(c, room * CHUNK_ITEMS * sizeof(Item) + 16, &early))) {
+					return bail(rc);
+				}
+				if (early_chunks) {
+					HIP_TRY(c, hipMemcpyAsync(early.p, c->arena.p, early_chunks * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sA));
+				}
+			}
 			if (n_def > 0 && status == 0) {
 				// pass 2: one wavefront per event that needs an indel sweep
 				a.defer = 0;
 				a.ev_list = (const u32*)c->deferred.p;
 				a.n_events = n_def;
-				const u64 want2 = ((u64)n_def + 3) / 4;
+				const u64 per_block = (u64)MACHINE_TPB / (u64)machine_wave_group();
+				const u64 want2 = ((u64)n_def + per_block - 1) / per_block;
 				const u64 cap2 = (u64)c->cu_count * 8;
 				const u64 b2 = want2 < cap2 ? want2 : cap2;
-				const size_t dyn2 = a.win_in_lds ? (size_t)a.win_bytes * 4 : 0;
+				// the wave kernel runs few events per block: window and workspace both fit in LDS
+				size_t dyn2 = a.win_in_lds ? (size_t)a.win_bytes * per_block : 0;
+				{
+					const u64 Wn = c->dp.node_window;
+					const u64 w16 = (Wn + 15) & ~15ull;
+					const u64 slab = Wn * 16 + w16 * 4 + w16 * 2 + w16 + w16;
+					const u64 win_area = ((u64)a.win_bytes * per_block + 15) & ~15ull;
+					if (win_area + slab * per_block <= 40 * 1024 && !getenv("NTEDIT_HIP_NO_LDS_WS")) {
+						a.win_in_lds = 1;
+						a.lds_ws_off = (u32)win_area;
+						a.lds_slab = (u32)slab;
+						dyn2 = (size_t)(win_area + slab * per_block);
+					}
+				}
+				if (const char* dbg = getenv("NTEDIT_HIP_PASS2_DEBUG")) {
+					a.p.debug_stop = (u32)atoi(dbg); // timing ablations; results are NOT valid
+				}
 				launch_k_machine_wave((unsigned)b2, dyn2, sB, a);
 				HIP_TRY(c, hipGetLastError());
 			}
@@ -1289,12 +1328,24 @@ ntedit_hip_polish_batch(
 			r->st.events = ev_total;
 			r->st.events_deferred = deferred_total;
 			r->arena_items = (size_t)used_chunks * CHUNK_ITEMS;
-			if ((rc = pin_take(c, r->arena_items * sizeof(Item) + 16, &r->arena_buf)) ||
-			    (rc = pin_take(c, ev_total * 4 + 16, &r->first_buf))) {
+			u64 have = 0; // chunks already on the host
+			if (early.p && early.cap >= r->arena_items * sizeof(Item) + 16) {
+				r->arena_buf = early;
+				early.p = nullptr;
+				early.cap = 0;
+				have = early_chunks;
+			} else {
+				pin_give(c, early);
+				if ((rc = pin_take(c, r->arena_items * sizeof(Item) + 16, &r->arena_buf))) {
+					return bail(rc);
+				}
+			}
+			if ((rc = pin_take(c, ev_total * 4 + 16, &r->first_buf))) {
 				return bail(rc);
 			}
-			if (used_chunks) {
-				HIP_TRY(c, hipMemcpyAsync(r->arena_buf.p, c->arena.p, r->arena_items * sizeof(Item), hipMemcpyDeviceToHost, sB));
+			if (used_chunks > have) {
+				const size_t off = (size_t)have * CHUNK_ITEMS * sizeof(Item);
+				HIP_TRY(c, hipMemcpyAsync((char*)r->arena_buf.p + off, (char*)c->arena.p + off, r->arena_items * sizeof(Item) - off, hipMemcpyDeviceToHost, sB));
 			}
 			if (ev_total) {
 				HIP_TRY(c, hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));

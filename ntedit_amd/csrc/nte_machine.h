@@ -145,7 +145,7 @@ struct Machine
 	wave_lane() const
 	{
 #if defined(__HIP_DEVICE_COMPILE__)
-		return e.wave_size > 1 ? (threadIdx.x & 63u) : 0u;
+		return threadIdx.x & (e.wave_size - 1u);
 #else
 		return 0;
 #endif
@@ -156,7 +156,10 @@ struct Machine
 	{
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (e.wave_size > 1) {
-			return __ballot(pred);
+			// the lanes of this event's group (a wavefront may carry 64 / wave_size events)
+			const u64 all = __ballot(pred);
+			const u32 shift = threadIdx.x & 63u & ~(e.wave_size - 1u);
+			return e.wave_size >= 64 ? all : ((all >> shift) & ((1ull << e.wave_size) - 1ull));
 		}
 #endif
 		return pred ? 1ull : 0ull;
@@ -167,7 +170,7 @@ struct Machine
 	{
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (e.wave_size > 1) {
-			return (u32)__shfl((int)v, (int)src, 64);
+			return (u32)__shfl((int)v, (int)src, (int)e.wave_size);
 		}
 #endif
 		(void)src;
@@ -181,10 +184,10 @@ struct Machine
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (e.wave_size > 1) {
 			u32 c = 0;
-			if ((threadIdx.x & 63u) == 0) {
+			if ((threadIdx.x & (e.wave_size - 1u)) == 0) {
 				c = atomicAdd(e.arena_next, 1u);
 			}
-			return (u32)__shfl((int)c, 0, 64);
+			return (u32)__shfl((int)c, 0, (int)e.wave_size);
 		}
 #endif
 		return NTE_ATOMIC_INC(e.arena_next);
@@ -1679,15 +1682,17 @@ struct Machine
 		}
 		if (e.wave_size > 1) {
 			const u32 lane = wave_lane();
-			bool present = false;
-			if (lane < L) {
-				HashState ts = hs;
-				for (u32 i = 0; i < lane; i++) {
-					hash_roll(ts, e.tab, win_o(i), win_i(i));
+			for (u32 base = 0; base < L; base += e.wave_size) {
+				bool present = false;
+				if (base + lane < L) {
+					HashState ts = hs;
+					for (u32 i = 0; i < base + lane; i++) {
+						hash_roll(ts, e.tab, win_o(i), win_i(i));
+					}
+					present = !screen_absent(ts);
 				}
-				present = !screen_absent(ts);
+				la_mask |= (u32)((wave_ballot(present) & 0xFFFFFFFFull) << base);
 			}
-			la_mask = (u32)(wave_ballot(present) & 0xFFFFFFFFull);
 			la_n = L;
 			return;
 		}
@@ -1962,6 +1967,9 @@ struct Machine
 				}
 			}
 			if (p.mode == 2 || b.edit_type != 1) {
+				if (p.debug_stop == 3) {
+					return; // timing ablation: everything up to the first indel sweep
+				}
 				if (e.defer_sweeps && p.ins_tries > 0) {
 					// the candidate sweep is ~100x the cost of everything else an event
 					// does; running it next to 63 cheap lanes would idle the wave, so the

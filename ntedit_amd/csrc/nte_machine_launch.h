@@ -28,6 +28,11 @@ struct MachineArgs
 	u8* ws_win;     // used when the windows do not fit in LDS
 	u32 win_bytes;  // window bytes per thread
 	u32 win_in_lds;
+	// wavefront-per-event kernel only: the per-event workspace (rope nodes, overlay, scratch
+	// strings) lives in LDS too, lds_slab bytes per event starting at byte lds_ws_off of the
+	// dynamic LDS (0 = use the global slabs)
+	u32 lds_ws_off;
+	u32 lds_slab;
 	// output
 	Item* arena;
 	u32* arena_next;
@@ -48,5 +53,7 @@ constexpr int MACHINE_TPB = 256;
 void launch_k_machine_thread(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);
 // one wavefront per event (sweep-only second pass)
 void launch_k_machine_wave(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);
+// lanes per event in that kernel (a 256-thread block runs 256 / group events at a time)
+int machine_wave_group();
 
 } // namespace nte

@@ -182,8 +182,7 @@ dev_filter(const DevFilter& f)
 {
 	Filter r;
 	r.data = f.data;
-	r.bits = f.counting ? f.nbytes : f.nbytes * 8; // counters vs bits
-	r.mask = (r.bits && (r.bits & (r.bits - 1)) == 0) ? r.bits - 1 : 0;
+	filter_set_size(r, f.counting ? f.nbytes : f.nbytes * 8); // counters vs bits
 	r.hash_num = f.hash_num;
 	r.counting = f.counting ? 1 : 0;
 	return r;
@@ -1315,6 +1314,15 @@ ntedit_hip_polish_batch(
 				    "[ntedit_hip] chunk %zu/%zu contigs %u-%u events %llu deferred %u pass1 %.3f ms pass2 %.3f ms arena %u "
 				    "status %u window %u\n",
 				    j + 1, n_ch, ch.c0, ch.c1, (unsigned long long)n_ev, n_def, p1, p2, h_tail[0], status, c->dp.node_window);
+			}
+			if (getenv("NTEDIT_HIP_DEBUG")) {
+				unsigned long long pr[16];
+				machine_wave_profile(pr);
+				if (pr[8]) {
+					fprintf(stderr, "[ntedit_hip] wave-kernel phase cycles/event (n=%llu): seed %llu presence %llu first-miss %llu later-miss %llu advance %llu loop %llu housekeeping %llu flush %llu; positions/event %.1f failing %.1f\n",
+					    pr[8], pr[0] / pr[8], pr[1] / pr[8], pr[2] / pr[8], pr[3] / pr[8], pr[4] / pr[8], pr[5] / pr[8], pr[6] / pr[8], pr[7] / pr[8],
+					    (double)pr[9] / (double)pr[8], (double)pr[10] / (double)pr[8]);
+				}
 			}
 			ev_total += n_ev;
 		}

@@ -11,7 +11,11 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#if defined(NTE_SOFT_INLINE)
+#define NTE_HD __host__ __device__ inline // code-size experiments: let the compiler decide
+#else
 #define NTE_HD __host__ __device__ __forceinline__
+#endif
 #define NTE_UNROLL _Pragma("unroll")
 #else
 #define NTE_HD inline
@@ -295,6 +299,7 @@ struct Filter
 	const u8* data; // plain BF: bit array, LSB-first within a byte; counting BF: 8-bit counters
 	u64 bits;       // number of addressable slots: bits (plain) or counters (counting)
 	u64 mask;       // bits - 1 when bits is a power of two, else 0
+	u64 magic;      // floor(2^64 / bits) when bits is not a power of two (filter_set_size)
 	u32 hash_num;
 	u32 counting;   // 1 = btllib KmerCountingBloomFilter8 (contains() = min counter)
 };
@@ -329,10 +334,42 @@ hash_extend(u64 base, const DevParams& p, unsigned i)
 	return t ^ (t >> MULTISHIFT);
 }
 
+// high 64 bits of a 64 x 64 product
+NTE_HD u64
+mulhi64(u64 a, u64 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __umul64hi(a, b);
+#else
+	return (u64)(((unsigned __int128)a * (unsigned __int128)b) >> 64);
+#endif
+}
+
+// geometry of a filter with `slots` addressable bits / counters
+inline void
+filter_set_size(Filter& f, u64 slots)
+{
+	f.bits = slots;
+	const bool pow2 = slots && (slots & (slots - 1)) == 0;
+	f.mask = pow2 ? slots - 1 : 0;
+	// floor(2^64 / slots) == floor((2^64 - 1) / slots) unless slots divides 2^64
+	f.magic = (slots && !pow2) ? 0xFFFFFFFFFFFFFFFFULL / slots : 0;
+}
+
 NTE_HD u64
 filter_slot(const Filter& f, u64 hv)
 {
-	return f.mask ? (hv & f.mask) : (hv % f.bits);
+	if (f.mask) {
+		return hv & f.mask;
+	}
+	// hv % bits without a division: q = floor(hv * magic / 2^64) is floor(hv / bits) or one
+	// less (magic > 2^64 / bits - 1), so one conditional subtraction finishes it
+	const u64 q = mulhi64(hv, f.magic);
+	u64 r = hv - q * f.bits;
+	if (r >= f.bits) {
+		r -= f.bits;
+	}
+	return r;
 }
 
 // counting filter: contains() returns the smallest of the h counters

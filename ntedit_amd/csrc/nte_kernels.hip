@@ -135,7 +135,7 @@ k_screen(
 #pragma unroll
 				for (int i = 0; i < (H > 0 ? H : 1); i++) {
 					const u64 hv = hash_extend(base, p, i);
-					slot[u][i] = POW2 ? (hv & f.mask) : (hv % f.bits);
+					slot[u][i] = POW2 ? (hv & f.mask) : filter_slot(f, hv);
 				}
 			}
 			const u8 out = (outw >> (8 * u)) & 0xFF;
@@ -341,7 +341,7 @@ k_bin(BinArgs a)
 #pragma unroll
 					for (int i = 0; i < H; i++) {
 						const u64 hv = hash_extend(base, a.p, i);
-						const u64 slot = POW2 ? (hv & a.f.mask) : (hv % a.f.bits);
+						const u64 slot = POW2 ? (hv & a.f.mask) : filter_slot(a.f, hv);
 						const u32 sl = (u32)(slot >> slog);
 						const u32 r = atomicAdd(&s_hist[sl], 1u);
 						if (MODE == BIN_WRITE && emit) {
@@ -476,7 +476,7 @@ k_bin_sort(BinArgs a)
 #pragma unroll
 					for (int i = 0; i < H; i++) {
 						const u64 hv = hash_extend(base, a.p, i);
-						const u64 slot = POW2 ? (hv & a.f.mask) : (hv % a.f.bits);
+						const u64 slot = POW2 ? (hv & a.f.mask) : filter_slot(a.f, hv);
 						const u32 sl = (u32)(slot >> slog);
 						const u32 r = atomicAdd(&s_cnt[sl], 1u);
 						if (place) {

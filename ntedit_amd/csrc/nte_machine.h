@@ -38,6 +38,40 @@ extern WorkCounters g_wc;
 #define NTE_COUNT(f, n) ((void)0)
 #endif
 
+// Phase timers of the wavefront-per-event kernel (build nte_machine_wave.hip with
+// -DNTE_PROFILE): shader cycles per phase, summed over events into g_prof[].
+#if defined(NTE_PROFILE)
+__device__ unsigned long long g_prof[16];
+#endif
+#if defined(NTE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define NTE_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, prof_cnt[4] = { 0, 0, 0, 0 }
+#define NTE_PROF_COUNT(slot) (prof_cnt[slot]++)
+#define NTE_PROF(slot)                                                    \
+	do {                                                                  \
+		const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+		prof_acc[slot] += now_ - prof_t;                                  \
+		prof_t = now_;                                                    \
+	} while (0)
+#define NTE_PROF_FLUSH                                                    \
+	do {                                                                  \
+		if ((threadIdx.x & (e.wave_size - 1u)) == 0) {                    \
+			for (int i_ = 0; i_ < 8; i_++) {                              \
+				atomicAdd(&g_prof[i_], prof_acc[i_]);                     \
+			}                                                             \
+			atomicAdd(&g_prof[8], 1ull);                                  \
+			for (int i_ = 0; i_ < 4; i_++) {                              \
+				atomicAdd(&g_prof[9 + i_], prof_cnt[i_]);                 \
+			}                                                             \
+		}                                                                 \
+	} while (0)
+#else
+#define NTE_PROF_DECL ((void)0)
+#define NTE_PROF_COUNT(slot) ((void)0)
+#define NTE_PROF(slot) ((void)0)
+#define NTE_PROF_FLUSH ((void)0)
+#endif
+
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define NTE_ATOMIC_INC(p) atomicAdd((p), 1u)
 #else
@@ -2041,7 +2075,9 @@ struct Machine
 			return;
 		}
 		bool first = true;
+		NTE_PROF_DECL;
 		while (true) {
+			NTE_PROF(first ? 0 : 5); // 0 = seeding, 5 = loop overhead
 			if ((u64)h_seq_i + p.k - 1 >= e.len) {
 				flags |= EV_TERMINAL;
 				cover_end = e.len;
@@ -2074,9 +2110,13 @@ struct Machine
 				}
 			}
 			const bool was_first = first;
+			NTE_PROF(1); // presence of the k-mer at the cursor (look-ahead included)
+			NTE_PROF_COUNT(0);
 			first = false;
 			if (missing) {
+				NTE_PROF_COUNT(1);
 				process_missing(char_in);
+				NTE_PROF(was_first ? 2 : 3); // first / later failing positions
 				la_n = la_i = 0; // the sequence may have changed: look ahead afresh
 				la_off = false;
 			}
@@ -2112,8 +2152,11 @@ struct Machine
 				cover_end = e.len;
 				break;
 			}
+			NTE_PROF(4); // advance
 			housekeeping();
+			NTE_PROF(6);
 		}
+		NTE_PROF(5);
 
 		// stream out what is left of the rope (only if an indel touched it)
 		if (rope_touched && !(flags & EV_DEFERRED)) {
@@ -2125,6 +2168,8 @@ struct Machine
 				emit_node(n);
 			}
 		}
+		NTE_PROF(7); // rope flush
+		NTE_PROF_FLUSH;
 	}
 
 	// seal the chunk chain; returns the first chunk (NONE32 if nothing was emitted)

@@ -25,8 +25,7 @@ make_filter(const uint8_t* data, uint64_t nbytes, uint32_t hash_num, bool counti
 {
 	Filter f;
 	f.data = data;
-	f.bits = counting ? nbytes : nbytes * 8;
-	f.mask = (f.bits && (f.bits & (f.bits - 1)) == 0) ? f.bits - 1 : 0;
+	filter_set_size(f, counting ? nbytes : nbytes * 8);
 	f.hash_num = hash_num;
 	f.counting = counting ? 1 : 0;
 	return f;

@@ -56,21 +56,6 @@ def cpu_baseline(job, pol, args):
     import helpers as H
 
     H.build_oracle()
-    lib = ctypes.CDLL(os.path.join(H.ORACLE_BUILD, "libntedit_oracle.so"))
-    lib.ora_polish_batch_flat.restype = ctypes.c_uint64
-
-    class OraParams(ctypes.Structure):
-        _fields_ = [("k", ctypes.c_uint), ("h", ctypes.c_uint), ("jump", ctypes.c_uint),
-                    ("min_contig_len", ctypes.c_uint), ("max_insertions", ctypes.c_uint),
-                    ("max_deletions", ctypes.c_uint), ("edit_threshold", ctypes.c_float),
-                    ("missing_threshold", ctypes.c_float), ("edit_ratio", ctypes.c_float),
-                    ("missing_ratio", ctypes.c_float), ("use_ratio", ctypes.c_int),
-                    ("insertion_cap", ctypes.c_uint), ("mode", ctypes.c_int), ("snv", ctypes.c_int),
-                    ("mask", ctypes.c_int), ("secbf", ctypes.c_int), ("min_threshold", ctypes.c_uint),
-                    ("max_threshold", ctypes.c_uint)]
-
-    p = OraParams()
-    lib.ora_params_default(ctypes.byref(p))
     # pick whole contigs, shortest first in input order, until the sample is filled
     want = int(args.cpu_sample_bases)
     idx, total = [], 0
@@ -95,10 +80,7 @@ def cpu_baseline(job, pol, args):
     bits = pol.filter_download(0)
     k, h, nbytes, _ = pol.filter_info(0)
     t0 = time.perf_counter()
-    done = lib.ora_polish_batch_flat(
-        ctypes.c_char_p(blob), offs.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), None,
-        ctypes.c_uint32(len(lens)), bits.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(nbytes),
-        ctypes.c_uint(h), ctypes.c_uint(k), None, ctypes.c_uint64(0), ctypes.c_uint(0), ctypes.byref(p), None, None)
+    done = H.oracle_polish_flat(blob, offs, lens, bits, h, k)
     dt = time.perf_counter() - t0
     return {"value": done / dt / 1e6, "unit": "Mbases/s", "cores": 1, "kind": "port",
             "sample": "%d contigs / %.1f Mbases of the same draft, same %d-byte filter, 1 thread, %.1f s" %

@@ -57,9 +57,14 @@ class Result:
     def write(self, blob, offsets, lens, names, fa_path, tsv_path, append=False, vcf_path=None, snv=False, annot=None):
         n = len(names)
         arr = (ctypes.c_char_p * max(n, 1))(*names)
-        buf = blob if isinstance(blob, (bytes, bytearray)) else bytes(blob)
+        if isinstance(blob, np.ndarray):  # (large batches: no copy)
+            buf = np.ascontiguousarray(blob, dtype=np.uint8)
+            ptr = ctypes.c_void_p(buf.ctypes.data)
+        else:
+            buf = blob if isinstance(blob, (bytes, bytearray)) else bytes(blob)
+            ptr = ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p)
         rc = self._lib.ntedit_hip_write_outputs_vcf(
-            self._h, ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p),
+            self._h, ptr,
             offsets.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), arr, n,
             fa_path.encode() if fa_path else None, tsv_path.encode() if tsv_path else None,
             vcf_path.encode() if vcf_path else None, 1 if append else 0, 1 if snv else 0, annot)
@@ -181,17 +186,21 @@ class Polisher:
         self._check(rc, "polish_batch")
         return Result(self._lib, res)
 
+    def write_tsv_header(self, tsv_path):
+        """header line of _changes.tsv for the loaded primary filter / current parameters"""
+        k, _, _, counting = self.filter_info(PRIMARY)
+        rc = self._lib.ntedit_hip_write_tsv_header(tsv_path.encode(), k, self.params.jump, int(counting))
+        if rc:
+            raise NtEditHipError("cannot write %s" % tsv_path)
+
     def polish_records(self, records, out_prefix, draft_name="", annot_path=None):
         """readAndCorrect at -t 1 for an in-memory list of (header, sequence): writes
         <prefix>_edited.fa, <prefix>_changes.tsv and <prefix>_variants.vcf; returns Stats."""
         blob, offs, lens, names = pack_batch(records, self.params.min_contig_len)
-        k, h, _, counting = self.filter_info(PRIMARY)
         tsv = out_prefix + "_changes.tsv"
         fa = out_prefix + "_edited.fa"
         vcf = out_prefix + "_variants.vcf"
-        rc = self._lib.ntedit_hip_write_tsv_header(tsv.encode(), k, self.params.jump, int(counting))
-        if rc:
-            raise NtEditHipError("cannot write %s" % tsv)
+        self.write_tsv_header(tsv)
         self._lib.ntedit_hip_write_vcf_header(vcf.encode(), draft_name.encode())
         open(fa, "wb").close()
         annot = ctypes.c_void_p()

@@ -85,9 +85,10 @@ class SyntheticJob:
     mutated draft, laid out as one batch (contigs separated by '\\n') in HBM."""
 
     def __init__(self, polisher, total_bases, k=25, hash_num=3, filter_bytes=1 << 32, seed=20251031,
-                 draft_seed=None, device="cuda", build_filter="alloc", n_runs=True):
+                 draft_seed=None, device="cuda", build_filter="alloc", n_runs=True, mutate=True):
         """build_filter: "alloc" = allocate a filter in the library and fill it; "insert" = fill the
-        filter the polisher already has (e.g. a shared tensor); False = leave the filter alone."""
+        filter the polisher already has (e.g. a shared tensor); False = leave the filter alone.
+        mutate=False keeps the draft identical to the truth genome (every k-mer is in the filter)."""
         self.total_bases = int(total_bases)
         dev = torch.device(device)
         lens = contig_lengths(total_bases, seed)
@@ -107,7 +108,7 @@ class SyntheticJob:
                 torch.cuda.synchronize(dev)
                 polisher.filter_insert(None, device_ptr=tb.data_ptr(), n=tb.numel())
                 del tb
-            d = codes_to_bytes(mutate_codes(t, gen_d))
+            d = codes_to_bytes(mutate_codes(t, gen_d) if mutate else t)
             if n_runs:
                 for p in range(5_000_000, d.numel() - 1000, 10_000_000):
                     d[p:p + 1000] = 78  # 'N'

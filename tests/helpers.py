@@ -78,6 +78,39 @@ def oracle_lib():
     return _oracle
 
 
+class OraParams(ctypes.Structure):
+    """ora_params of oracle/ntedit_oracle.h"""
+    _fields_ = [("k", ctypes.c_uint), ("h", ctypes.c_uint), ("jump", ctypes.c_uint),
+                ("min_contig_len", ctypes.c_uint), ("max_insertions", ctypes.c_uint),
+                ("max_deletions", ctypes.c_uint), ("edit_threshold", ctypes.c_float),
+                ("missing_threshold", ctypes.c_float), ("edit_ratio", ctypes.c_float),
+                ("missing_ratio", ctypes.c_float), ("use_ratio", ctypes.c_int),
+                ("insertion_cap", ctypes.c_uint), ("mode", ctypes.c_int), ("snv", ctypes.c_int),
+                ("mask", ctypes.c_int), ("secbf", ctypes.c_int), ("min_threshold", ctypes.c_uint),
+                ("max_threshold", ctypes.c_uint)]
+
+
+def oracle_polish_flat(blob, offsets, lens, bits, hash_num, k, names=None, fa_path=None, tsv_path=None):
+    """The oracle over an in-memory batch and an in-memory filter (default parameters, 1 thread);
+    returns the number of bases it processed."""
+    import numpy as np
+    lib = oracle_lib()
+    lib.ora_polish_batch_flat.restype = ctypes.c_uint64
+    p = OraParams()
+    lib.ora_params_default(ctypes.byref(p))
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    arr = None
+    if names is not None:
+        arr = (ctypes.c_char_p * max(len(names), 1))(*names)
+    return lib.ora_polish_batch_flat(
+        ctypes.c_char_p(blob), offsets.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), arr,
+        ctypes.c_uint32(len(lens)), bits.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bits.size),
+        ctypes.c_uint(hash_num), ctypes.c_uint(k), None, ctypes.c_uint64(0), ctypes.c_uint(0), ctypes.byref(p),
+        fa_path.encode() if fa_path else None, tsv_path.encode() if tsv_path else None)
+
+
 _hostsim = None
 
 

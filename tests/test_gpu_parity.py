@@ -259,3 +259,112 @@ def test_cli_drop_in(tmp_path, oracle_build):
                                                                max_deletions=12), str(tmp_path / "o3"))
     assert filecmp.cmp(str(tmp_path / "o3_changes.tsv"), str(tmp_path / "g2_changes.tsv"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "o3_edited.fa"), str(tmp_path / "g2_edited.fa"), shallow=False)
+
+
+def _sample_records(fa_path, tsv_path, want):
+    """FASTA records / TSV rows of the contigs named in `want` (streamed: the files are GB-sized)"""
+    fa, tsv = {}, {w: [] for w in want}
+    with open(fa_path, "rb") as f:
+        while True:
+            hdr = f.readline()
+            if not hdr:
+                break
+            seq = f.readline()
+            name = hdr[1:].split()[0]
+            if name in tsv:
+                fa[name] = (hdr, seq)
+    with open(tsv_path, "rb") as f:
+        f.readline()
+        for line in f:
+            name = line.split(b"\t", 1)[0]
+            if name in tsv:
+                tsv[name].append(line)
+    return fa, tsv
+
+
+def test_full_size_properties(tmp_path, oracle_build):
+    """BASELINE.json's full configuration (3 Gbp draft, k=25, 4 GiB filter), where the oracle cannot
+    run the whole job: size-independent properties plus an oracle spot check.
+      1. no false negatives: an unmutated draft has no absent k-mer and gets no edit;
+      2. partition independence: the per-kind edit counts of the whole batch equal the sum over a
+         2-way split of its contigs;
+      3. three contigs (shortest, 1/8 quantile, median length) picked from the full-batch result are byte-identical to the oracle's output
+         for them (same 4 GiB filter, downloaded from HBM)."""
+    import torch
+    import ntedit_amd
+    from ntedit_amd.synth import SyntheticJob
+
+    total = float(os.environ.get("NTEDIT_FULL_BASES", "3e9"))
+    fbytes = int(os.environ.get("NTEDIT_FULL_FILTER", str(1 << 32)))
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.set_params(ntedit_amd.default_params())
+        # 1. truth genome against its own filter
+        job = SyntheticJob(pol, total, k=25, hash_num=3, filter_bytes=fbytes, mutate=False, n_runs=False)
+        res = pol.polish_batch(None, job.offsets, job.lens, device_ptr=job.device_ptr, n=job.n_bytes)
+        st = res.stats()
+        assert st.bases == job.n_bytes
+        assert (st.absent_kmers, st.events, st.substitutions, st.insertions, st.deletions) == (0, 0, 0, 0, 0)
+        res.free()
+        del job
+        torch.cuda.empty_cache()
+
+        # the mutated draft of the same genome (the filter is already built)
+        job = SyntheticJob(pol, total, k=25, hash_num=3, filter_bytes=fbytes, build_filter=False)
+        res = pol.polish_batch(None, job.offsets, job.lens, device_ptr=job.device_ptr, n=job.n_bytes)
+        # render the whole batch (the per-kind edit counts are produced by the renderer)
+        nc = len(job.lens)
+        names = [b"contig%d" % i for i in range(nc)]
+        host = job.batch.cpu().numpy()
+        fa, tsv = str(tmp_path / "full_edited.fa"), str(tmp_path / "full_changes.tsv")
+        pol.write_tsv_header(tsv)
+        res.write(host, job.offsets, job.lens, names, fa, tsv, append=True)
+        st = res.stats()
+        res.free()
+        whole = (st.absent_kmers, st.substitutions, st.insertions, st.deletions, st.events_applied)
+        assert st.insertions > 0 and st.deletions > 0
+        # the synthetic error rates: 0.1% substitutions, 0.01% indels -- nearly all are repaired
+        assert 0.8e-3 * job.n_bases < st.substitutions < 1.2e-3 * job.n_bases
+
+        # 2. two halves, polished and rendered (to nowhere) separately
+        parts = []
+        for lo, hi in ((0, nc // 2), (nc // 2, nc)):
+            o0 = int(job.offsets[lo])
+            o1 = int(job.offsets[hi - 1]) + int(job.lens[hi - 1]) + 1
+            offs_h = job.offsets[lo:hi] - np.uint64(o0)
+            half = job.batch[o0:o1].clone()  # (device batches have to start 16-byte aligned)
+            torch.cuda.synchronize()
+            r = pol.polish_batch(None, offs_h, job.lens[lo:hi], device_ptr=half.data_ptr(), n=o1 - o0)
+            del half
+            r.write(host[o0:o1], offs_h, job.lens[lo:hi], names[lo:hi], None, None)
+            s = r.stats()
+            parts.append((s.absent_kmers, s.substitutions, s.insertions, s.deletions, s.events_applied))
+            r.free()
+        assert tuple(a + b for a, b in zip(*parts)) == whole
+
+        # 3. compare a sample of contigs with the oracle
+        order = np.argsort(job.lens, kind="stable")
+        pick = sorted({int(order[0]), int(order[len(order) // 8]), int(order[len(order) // 2])})
+        blob, offs, lens, pos = [], [], [], 0
+        for i in pick:
+            o, l = int(job.offsets[i]), int(job.lens[i])
+            blob.append(host[o:o + l + 1].tobytes())
+            offs.append(pos)
+            lens.append(l)
+            pos += l + 1
+        bits = pol.filter_download(0)
+        k, h, nbytes, _ = pol.filter_info(0)
+        ofa, otsv = str(tmp_path / "ora_edited.fa"), str(tmp_path / "ora_changes.tsv")
+        done = H.oracle_polish_flat(b"".join(blob), offs, lens, bits, h, k, names=[names[i] for i in pick],
+                                    fa_path=ofa, tsv_path=otsv)
+        assert done == sum(lens)
+        want = [names[i] for i in pick]
+        got_fa, got_tsv = _sample_records(fa, tsv, want)
+        exp_fa, exp_tsv = _sample_records(ofa, otsv, want)
+        assert set(got_fa) == set(want) == set(exp_fa)
+        for w in want:
+            assert got_fa[w] == exp_fa[w], w
+            assert got_tsv[w] == exp_tsv[w], w
+        assert sum(len(v) for v in exp_tsv.values()) > 100
+    finally:
+        pol.close()

@@ -202,6 +202,12 @@ int ntedit_hip_write_outputs_vcf(
     int snv,
     const ntedit_hip_annot* annot);
 
+/* Host threads used by write_outputs() to render contigs concurrently (the reference's -t;
+ * output order and bytes do not depend on it).  0 = default (up to 8).  Process-wide.
+ * A result may be rendered and freed on another thread than the one that runs
+ * polish_batch() on the same context. */
+void ntedit_hip_set_host_threads(unsigned n);
+
 /* timings of the last screen()/filter_insert() call (HIP events, ms) */
 float ntedit_hip_last_kernel_ms(const ntedit_hip_ctx* ctx);
 

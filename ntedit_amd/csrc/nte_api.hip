@@ -10,10 +10,12 @@
 #include "../host/params.h"
 #include "../host/render.h"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,6 +40,8 @@ struct DevFilter
 } // namespace
 
 // page-locked host buffer (D2H at PCIe speed, no zero-fill); recycled through the context
+static std::atomic<unsigned> g_host_threads(0); // ntedit_hip_set_host_threads()
+
 struct PinBuf
 {
 	void* p = nullptr;
@@ -65,6 +69,7 @@ struct ntedit_hip_ctx
 	DevBuf bin_records, bin_totals, bin_bases, bin_work;
 	u32 cu_count = 256;
 	std::vector<PinBuf> pin_pool;
+	std::mutex pin_mu;
 };
 
 struct ntedit_hip_result
@@ -128,6 +133,7 @@ ensure(ntedit_hip_ctx* c, DevBuf& b, size_t bytes)
 int
 pin_take(ntedit_hip_ctx* c, size_t bytes, PinBuf* out)
 {
+	std::lock_guard<std::mutex> lk(c->pin_mu); // results are freed from other threads
 	int best = -1;
 	for (size_t i = 0; i < c->pin_pool.size(); i++) {
 		if (c->pin_pool[i].cap >= bytes && (best < 0 || c->pin_pool[i].cap < c->pin_pool[best].cap)) {
@@ -159,6 +165,7 @@ pin_give(ntedit_hip_ctx* c, PinBuf& b)
 		return;
 	}
 	if (c) {
+		std::lock_guard<std::mutex> lk(c->pin_mu);
 		c->pin_pool.push_back(b);
 	} else {
 		(void)hipHostFree(b.p);
@@ -1510,6 +1517,7 @@ ntedit_hip_write_outputs_vcf(
 	ntedit_hip_result* rw = const_cast<ntedit_hip_result*>(r);
 	rw->rst = nte_host::RenderStats();
 	nte_host::RenderOptions opt;
+	opt.threads = g_host_threads.load();
 	opt.snv = snv != 0;
 	opt.annot = annot ? annot->a : nullptr;
 	int rc = nte_host::render_batch(
@@ -1563,6 +1571,12 @@ ntedit_hip_write_tsv_header(const char* tsv_path, uint32_t k, uint32_t jump, int
 	}
 	nte_host::write_tsv_header(tsv, k, jump, counting != 0);
 	return fclose(tsv) == 0 ? 0 : NTEDIT_E_IO;
+}
+
+void
+ntedit_hip_set_host_threads(unsigned n)
+{
+	g_host_threads.store(n);
 }
 
 float

@@ -2,10 +2,13 @@
 
 #include <cctype>
 #include <cstdlib>
+#include <cstring>
 
 namespace nte_host {
 
-static const int BUFSZ = 1 << 18;
+// large reads go straight from the file into buf_ when the input is not compressed
+// (zlib copies directly once a request is at least twice its own buffer)
+static const int BUFSZ = 4 << 20;
 
 FastaReader::FastaReader(const char* path)
   : f_(gzopen(path, "r"))
@@ -14,9 +17,11 @@ FastaReader::FastaReader(const char* path)
   , end_(0)
   , eof_(false)
   , last_char_(0)
+  , hit_nl_(false)
+  , failed_(false)
 {
 	if (f_) {
-		gzbuffer(f_, 1 << 20);
+		gzbuffer(f_, 1 << 17);
 	}
 }
 
@@ -28,57 +33,56 @@ FastaReader::~FastaReader()
 	free(buf_);
 }
 
+bool
+FastaReader::fill_()
+{
+	if (eof_) {
+		return false;
+	}
+	begin_ = 0;
+	end_ = gzread(f_, buf_, BUFSZ);
+	if (end_ <= 0) {
+		end_ = 0;
+		eof_ = true;
+		return false;
+	}
+	return true;
+}
+
 int
 FastaReader::getc_()
 {
-	if (begin_ >= end_) {
-		if (eof_) {
-			return -1;
-		}
-		begin_ = 0;
-		end_ = gzread(f_, buf_, BUFSZ);
-		if (end_ <= 0) {
-			end_ = 0;
-			eof_ = true;
-			return -1;
-		}
+	if (begin_ >= end_ && !fill_()) {
+		return -1;
 	}
 	return buf_[begin_++];
 }
 
-// reads up to (not including) the next '\n'; strips one trailing '\r'
+// appends the rest of the current line (up to, not including, '\n') to `out`; with strip_cr,
+// then drops one trailing '\r' if the string that starts at out[base] is longer than one
+// character (kseq's ks_getuntil2 rule for line reads, applied to the accumulated string)
 bool
-FastaReader::getline_(std::string& out, bool append)
+FastaReader::getline_(std::string& out, size_t base, bool strip_cr)
 {
-	if (!append) {
-		out.clear();
-	}
 	bool any = false;
+	hit_nl_ = false;
 	for (;;) {
-		if (begin_ >= end_) {
-			if (eof_) {
-				break;
-			}
-			begin_ = 0;
-			end_ = gzread(f_, buf_, BUFSZ);
-			if (end_ <= 0) {
-				end_ = 0;
-				eof_ = true;
-				break;
-			}
+		if (begin_ >= end_ && !fill_()) {
+			break;
 		}
 		any = true;
-		int i = begin_;
-		while (i < end_ && buf_[i] != '\n') {
-			i++;
-		}
-		out.append((const char*)buf_ + begin_, (size_t)(i - begin_));
-		begin_ = i + 1;
-		if (i < end_) {
+		const unsigned char* s = buf_ + begin_;
+		const size_t avail = (size_t)(end_ - begin_);
+		const unsigned char* nl = (const unsigned char*)memchr(s, '\n', avail);
+		const size_t n = nl ? (size_t)(nl - s) : avail;
+		out.append((const char*)s, n);
+		begin_ += (int)n + (nl ? 1 : 0);
+		if (nl) {
+			hit_nl_ = true;
 			break;
 		}
 	}
-	if (out.size() > 1 && out.back() == '\r') {
+	if (strip_cr && out.size() - base > 1 && out.back() == '\r') {
 		out.pop_back();
 	}
 	return any;
@@ -88,6 +92,9 @@ bool
 FastaReader::next(std::string& header, std::string& seq)
 {
 	int c;
+	if (failed_) {
+		return false;
+	}
 	if (last_char_ == 0) {
 		while ((c = getc_()) != -1 && c != '>' && c != '@') {
 		}
@@ -96,39 +103,59 @@ FastaReader::next(std::string& header, std::string& seq)
 		}
 		last_char_ = c;
 	}
-	std::string line;
-	if (!getline_(line, false) && eof_) {
+	line_.clear();
+	if (!getline_(line_, 0, false) && eof_) {
 		return false;
 	}
-	// name up to the first whitespace; comment = rest of the line
+	// name = up to the first whitespace character; if that character was not the newline,
+	// comment = the rest of the line (lib/kseq.h:189-190).  Both are consumed as C strings
+	// (ntedit.cpp:2223-2226).
 	size_t nl = 0;
-	while (nl < line.size() && !isspace((unsigned char)line[nl])) {
+	while (nl < line_.size() && !isspace((unsigned char)line_[nl])) {
 		nl++;
 	}
-	header.assign(line, 0, nl);
-	if (nl + 1 < line.size()) {
-		header.push_back(' ');
-		header.append(line, nl + 1, std::string::npos);
+	header.assign(line_, 0, strnlen(line_.data(), nl));
+	if (nl < line_.size()) {
+		size_t cl = line_.size() - (nl + 1);
+		if (cl > 1 && line_.back() == '\r') {
+			cl--;
+		}
+		if (cl) {
+			header.push_back(' ');
+			header.append(line_, nl + 1, strnlen(line_.data() + nl + 1, cl));
+		}
 	}
-	seq.clear();
+	const size_t base = seq.size();
 	last_char_ = 0;
 	while ((c = getc_()) != -1 && c != '>' && c != '+' && c != '@') {
 		if (c == '\n') {
 			continue;
 		}
 		seq.push_back((char)c);
-		getline_(seq, true);
+		getline_(seq, base, true);
 	}
 	if (c == '>' || c == '@') {
 		last_char_ = c;
 	}
 	if (c == '+') {
-		// FASTQ: skip the '+' line and as many quality characters as bases
-		std::string q;
-		getline_(q, false);
-		size_t have = 0;
-		while (have < seq.size() && getline_(q, false)) {
-			have += q.size();
+		// FASTQ: skip the rest of the '+' line, then quality lines until there are as many
+		// quality characters as bases (lib/kseq.h:205-212)
+		const size_t want = seq.size() - base;
+		line_.clear();
+		getline_(line_, 0, false);
+		if (!hit_nl_) {
+			failed_ = true; // kseq_read() = -2 (no quality string): the reference stops reading
+			seq.resize(base);
+			return false;
+		}
+		line_.clear();
+		while (getline_(line_, 0, true) && line_.size() < want) {
+		}
+		last_char_ = 0;
+		if (line_.size() != want) {
+			failed_ = true; // kseq_read() = -2 (truncated quality string)
+			seq.resize(base);
+			return false;
 		}
 	}
 	return true;

@@ -15,17 +15,21 @@ class FastaReader
 	explicit FastaReader(const char* path);
 	~FastaReader();
 	bool ok() const { return f_ != nullptr; }
-	// reads the next record; header = name [+ " " + comment]; false at EOF
+	// reads the next record; header = name [+ " " + comment]; the sequence is APPENDED to seq
+	// (so a batch can be assembled without an intermediate copy); false at EOF
 	bool next(std::string& header, std::string& seq);
 
   private:
+	bool fill_();
 	int getc_();
-	bool getline_(std::string& out, bool append);
+	bool getline_(std::string& out, size_t base, bool strip_cr);
+	std::string line_;
 	gzFile f_;
 	unsigned char* buf_;
 	int begin_, end_;
 	bool eof_;
 	int last_char_;
+	bool hit_nl_, failed_;
 };
 
 } // namespace nte_host

@@ -3,9 +3,9 @@
 // Keeps the reference's command-line surface (ntedit.cpp:135-169, 2276-2364):
 //   -t -f -r -e -b -z -i -d -x -y -X -Y -c -j -m -s -l -a -v -p -q -k --help --version
 // (-k is accepted and ignored, exactly like the reference: k comes from the
-// Bloom filter header; -c is parsed and overwritten by k*1.5; -t has no effect
-// because contigs are processed on the GPU, output order is the input order,
-// i.e. the reference at -t 1).  Reads the draft with kseq semantics, batches
+// Bloom filter header; -c is parsed and overwritten by k*1.5; -t sets the host
+// threads that render the output, contigs themselves are polished on the GPU and
+// the output order is the input order, i.e. the reference at -t 1).  Reads the draft with kseq semantics, batches
 // contigs, calls the C ABI (include/ntedit_hip.h) and writes
 // <prefix>_edited.fa and <prefix>_changes.tsv byte-identically to the
 // reference, plus <prefix>_variants.vcf (the ##fileDate line carries today's date, as in
@@ -14,6 +14,10 @@
 #include "fasta.h"
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,7 +33,7 @@
 static const char USAGE[] = PROGRAM
     " (MI355X HIP hot path)\n\n"
     " Options:\n"
-    "	-t,	number of threads (accepted; contigs are polished on the GPU)\n"
+    "	-t,	number of host threads rendering the output (contigs are polished on the GPU)\n"
     "	-f,	draft genome assembly (FASTA, Multi-FASTA, and/or gzipped compatible), REQUIRED\n"
     "	-r,	Bloom filter (BF) or counting BF (CBF) file (btllib format, e.g. from ntStat v1.0.0+), REQUIRED\n"
     "	-e,	secondary BF with k-mers to reject, OPTIONAL\n"
@@ -142,6 +146,39 @@ struct Batch
 	}
 };
 
+struct Work
+{
+	Batch b;
+	ntedit_hip_result* res = nullptr;
+};
+
+// blocking hand-over queue between the pipeline stages (nullptr = end of stream)
+class Channel
+{
+  public:
+	void push(Work* w)
+	{
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			q_.push_back(w);
+		}
+		cv_.notify_one();
+	}
+	Work* pop()
+	{
+		std::unique_lock<std::mutex> lk(mu_);
+		cv_.wait(lk, [&]() { return !q_.empty(); });
+		Work* w = q_.front();
+		q_.pop_front();
+		return w;
+	}
+
+  private:
+	std::mutex mu_;
+	std::condition_variable cv_;
+	std::deque<Work*> q_;
+};
+
 int
 main(int argc, char** argv)
 {
@@ -149,6 +186,7 @@ main(int argc, char** argv)
 	ntedit_hip_params_default(&p);
 	std::string draft, bf, bfrep, prefix, vcf;
 	unsigned nthreads = 4, ignored_u = 0;
+	bool threads_given = false;
 	int verbose = 0, gpu = 0, report = 0;
 	unsigned long long batch_bases = 1ull << 30;
 	unsigned shard_i = 0, shard_n = 1;
@@ -160,6 +198,7 @@ main(int argc, char** argv)
 			break;
 		case 't':
 			parse(c, optarg, nthreads);
+			threads_given = true;
 			break;
 		case 'f':
 			parse(c, optarg, draft);
@@ -381,88 +420,155 @@ main(int argc, char** argv)
 		fprintf(stderr, PROGRAM ": error: `%s': cannot open\n", draft.c_str());
 		exit(EXIT_FAILURE);
 	}
-	Batch b;
-	std::string hdr, seq;
+	if (threads_given) {
+		ntedit_hip_set_host_threads(nthreads); // -t: contigs rendered concurrently
+	}
 	unsigned long long n_contigs = 0, total_bases = 0;
-	double ms_gpu = 0, ms_screen = 0;
+	double ms_gpu = 0, ms_screen = 0, s_call = 0, s_write = 0, s_read = 0;
 	ntedit_hip_stats tot;
 	memset(&tot, 0, sizeof tot);
 	auto t0 = std::chrono::steady_clock::now();
-	auto flush = [&]() {
-		if (b.names.empty()) {
-			return;
+
+	// Three stages, one batch each at a time: this thread's reader helper parses the draft
+	// into batch N+1 while the GPU polishes batch N and the writer renders batch N-1.
+	// Output order = input order (the reference at -t 1).
+	Work pool[3];
+	Channel free_q, gpu_q, write_q;
+	for (Work& w : pool) {
+		free_q.push(&w);
+	}
+	for (Work& w : pool) {
+		// (address space only: pages are touched as the batch fills)
+		w.b.blob.reserve((size_t)(batch_bases < (1ull << 32) ? batch_bases : (1ull << 32)) + (1 << 20));
+	}
+	std::thread reader_thread([&]() {
+		std::string hdr;
+		unsigned long long idx = 0;
+		Work* w = free_q.pop();
+		auto tr0 = std::chrono::steady_clock::now();
+		auto hand_over = [&](Work* next) {
+			s_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+			gpu_q.push(w);
+			w = next;
+			tr0 = std::chrono::steady_clock::now();
+		};
+		for (;;) {
+			Batch& b = w->b;
+			const size_t before = b.blob.size();
+			if (!reader.next(hdr, b.blob)) {
+				break;
+			}
+			n_contigs++;
+			// strings holding an embedded NUL end there in the reference (contigSeq = seq->seq.s)
+			const void* z = memchr(b.blob.data() + before, 0, b.blob.size() - before);
+			if (z) {
+				b.blob.resize((size_t)((const char*)z - b.blob.data()));
+			}
+			const size_t len = b.blob.size() - before;
+			bool keep = false;
+			if (len >= p.min_contig_len) { // ntedit.cpp:2242
+				keep = shard_n == 1 || (idx % shard_n) == shard_i;
+				idx++;
+			}
+			if (!keep) {
+				b.blob.resize(before);
+			} else {
+				if (len > 0xFFFFFFF0ull) {
+					fprintf(stderr, PROGRAM ": error: contig longer than 2^32 bases\n");
+					fflush(nullptr);
+					_exit(EXIT_FAILURE);
+				}
+				if (!b.names.empty() && b.blob.size() + 1 > batch_bases) {
+					// the batch is full: this contig opens the next one
+					s_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+					Work* nx = free_q.pop();
+					tr0 = std::chrono::steady_clock::now();
+					nx->b.blob.assign(b.blob, before, std::string::npos);
+					b.blob.resize(before);
+					hand_over(nx);
+					Batch& nb = w->b;
+					nb.offs.push_back(0);
+					nb.lens.push_back((uint32_t)len);
+					nb.names.push_back(hdr);
+					nb.blob.push_back('\n');
+				} else {
+					b.offs.push_back(before);
+					b.lens.push_back((uint32_t)len);
+					b.names.push_back(hdr);
+					b.blob.push_back('\n');
+				}
+				total_bases += len;
+			}
+			if (n_contigs % 1000000 == 0) {
+				printf("Processed %llu\n", n_contigs);
+			}
 		}
-		ntedit_hip_result* res = nullptr;
+		hand_over(nullptr); // (possibly empty) last batch
+		gpu_q.push(nullptr);
+	});
+	std::thread writer_thread([&]() {
+		while (Work* w = write_q.pop()) {
+			Batch& b = w->b;
+			auto tw0 = std::chrono::steady_clock::now();
+			std::vector<const char*> names(b.names.size());
+			for (size_t i = 0; i < b.names.size(); i++) {
+				names[i] = b.names[i].c_str();
+			}
+			int rc = ntedit_hip_write_outputs_vcf(w->res, b.blob.data(), b.offs.data(), b.lens.data(), names.data(),
+			                                      (uint32_t)names.size(), fa_path.c_str(), tsv_path.c_str(),
+			                                      vcf_path.c_str(), 1, p.snv, annot);
+			if (rc != 0) {
+				fprintf(stderr, PROGRAM ": error: cannot write outputs\n");
+				fflush(nullptr);
+				_exit(EXIT_FAILURE);
+			}
+			ntedit_hip_stats st;
+			ntedit_hip_result_stats(w->res, &st);
+			ms_gpu += st.ms_total;
+			ms_screen += st.ms_screen;
+			tot.events += st.events;
+			tot.events_applied += st.events_applied;
+			tot.absent_kmers += st.absent_kmers;
+			tot.substitutions += st.substitutions;
+			tot.insertions += st.insertions;
+			tot.deletions += st.deletions;
+			ntedit_hip_result_free(w->res);
+			w->res = nullptr;
+			b.clear();
+			s_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+			free_q.push(w);
+		}
+	});
+	while (Work* w = gpu_q.pop()) {
+		Batch& b = w->b;
+		if (b.names.empty()) {
+			b.clear();
+			free_q.push(w);
+			continue;
+		}
+		auto tc0 = std::chrono::steady_clock::now();
 		int rc = ntedit_hip_polish_batch(ctx, b.blob.data(), b.blob.size(), b.offs.data(), b.lens.data(),
-		                                 (uint32_t)b.names.size(), 0, &res);
+		                                 (uint32_t)b.names.size(), 0, &w->res);
 		if (rc != 0) {
 			fprintf(stderr, PROGRAM ": error: %s\n", ntedit_hip_last_error(ctx));
-			exit(EXIT_FAILURE);
+			fflush(nullptr);
+			_exit(EXIT_FAILURE);
 		}
-		std::vector<const char*> names(b.names.size());
-		for (size_t i = 0; i < b.names.size(); i++) {
-			names[i] = b.names[i].c_str();
-		}
-		rc = ntedit_hip_write_outputs_vcf(res, b.blob.data(), b.offs.data(), b.lens.data(), names.data(),
-		                                  (uint32_t)names.size(), fa_path.c_str(), tsv_path.c_str(), vcf_path.c_str(), 1,
-		                                  p.snv, annot);
-		if (rc != 0) {
-			fprintf(stderr, PROGRAM ": error: cannot write outputs\n");
-			exit(EXIT_FAILURE);
-		}
-		ntedit_hip_stats st;
-		ntedit_hip_result_stats(res, &st);
-		ms_gpu += st.ms_total;
-		ms_screen += st.ms_screen;
-		tot.events += st.events;
-		tot.events_applied += st.events_applied;
-		tot.absent_kmers += st.absent_kmers;
-		tot.substitutions += st.substitutions;
-		tot.insertions += st.insertions;
-		tot.deletions += st.deletions;
-		ntedit_hip_result_free(res);
-		b.clear();
-	};
-	unsigned long long idx = 0;
-	while (reader.next(hdr, seq)) {
-		n_contigs++;
-		// strings holding an embedded NUL end there in the reference (contigSeq = seq->seq.s)
-		size_t z = seq.find('\0');
-		if (z != std::string::npos) {
-			seq.resize(z);
-		}
-		if (seq.size() >= p.min_contig_len) { // ntedit.cpp:2242
-			if (shard_n == 1 || (idx % shard_n) == shard_i) {
-				if (seq.size() > 0xFFFFFFF0ull) {
-					fprintf(stderr, PROGRAM ": error: contig longer than 2^32 bases\n");
-					exit(EXIT_FAILURE);
-				}
-				if (!b.names.empty() && b.blob.size() + seq.size() + 1 > batch_bases) {
-					flush();
-				}
-				b.offs.push_back(b.blob.size());
-				b.lens.push_back((uint32_t)seq.size());
-				b.names.push_back(hdr);
-				b.blob.append(seq);
-				b.blob.push_back('\n');
-				total_bases += seq.size();
-			}
-			idx++;
-		}
-		if (n_contigs % 1000000 == 0) {
-			printf("Processed %llu\n", n_contigs);
-		}
+		s_call += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
+		write_q.push(w);
 	}
-	flush();
+	write_q.push(nullptr);
+	reader_thread.join();
+	writer_thread.join();
 	auto t1 = std::chrono::steady_clock::now();
 	time(&rawtime);
 	printf("---------- process complete                         : %s", ctime(&rawtime));
 	if (report) {
 		double s = std::chrono::duration<double>(t1 - t0).count();
-		printf("{\"bases\": %llu, \"seconds\": %.6f, \"gpu_ms\": %.3f, \"screen_ms\": %.3f, \"events\": %llu, "
+		printf("{\"bases\": %llu, \"seconds\": %.6f, \"read_s\": %.3f, \"polish_call_s\": %.3f, \"write_s\": %.3f, \"gpu_ms\": %.3f, \"screen_ms\": %.3f, \"events\": %llu, "
 		       "\"events_applied\": %llu, \"absent_kmers\": %llu, \"substitutions\": %llu, \"insertions\": %llu, "
 		       "\"deletions\": %llu}\n",
-		       total_bases, s, ms_gpu, ms_screen, (unsigned long long)tot.events,
+		       total_bases, s, s_read, s_call, s_write, ms_gpu, ms_screen, (unsigned long long)tot.events,
 		       (unsigned long long)tot.events_applied, (unsigned long long)tot.absent_kmers,
 		       (unsigned long long)tot.substitutions, (unsigned long long)tot.insertions,
 		       (unsigned long long)tot.deletions);

@@ -1,12 +1,21 @@
-// render.cpp -- see render.h.  Host-side, single pass over the batch.
+// render.cpp -- see render.h.  Host-side.  Every contig is rendered independently (worker
+// threads) into text buffers plus a list of spans of the draft; the calling thread writes
+// them to the three streams in input order.
 #include "render.h"
 
 #include <cctype>
 #include <cmath>
 #include <cstring>
 #include <ctime>
+#include <atomic>
+#include <condition_variable>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <string>
+#include <cerrno>
+#include <sys/uio.h>
+#include <unistd.h>
 #include <zlib.h>
 
 namespace nte_host {
@@ -19,14 +28,14 @@ class Annotations
   public:
 	std::map<std::string, std::string> m;
 	// "^" + INFO of the variant id, or "^NA" (clinvar[id].empty() -> NA in the reference)
-	void put(FILE* vcf, const std::string& id) const
+	void put(std::string& vcf, const std::string& id) const
 	{
 		auto it = m.find(id);
-		fputc('^', vcf);
+		vcf.push_back('^');
 		if (it != m.end() && !it->second.empty()) {
-			fputs(it->second.c_str(), vcf);
+			vcf += it->second.c_str();
 		} else {
-			fputs("NA", vcf);
+			vcf += "NA";
 		}
 	}
 };
@@ -77,12 +86,12 @@ annotations_free(Annotations* a)
 }
 
 static void
-put_annot(FILE* vcf, const Annotations* a, const std::string& id)
+put_annot(std::string& vcf, const Annotations* a, const std::string& id)
 {
 	if (a) {
 		a->put(vcf, id);
 	} else {
-		fputs("^NA", vcf);
+		vcf += "^NA";
 	}
 }
 
@@ -94,6 +103,32 @@ upper(const char* s, size_t n)
 		c = (char)toupper((unsigned char)c);
 	}
 	return r;
+}
+
+// decimal text of an unsigned / signed integer (what %u / %d print)
+static void
+put_u(std::string& o, uint64_t v)
+{
+	char tmp[24];
+	int n = 0;
+	do {
+		tmp[n++] = (char)('0' + v % 10);
+		v /= 10;
+	} while (v);
+	while (n) {
+		o.push_back(tmp[--n]);
+	}
+}
+
+static void
+put_i(std::string& o, int64_t v)
+{
+	if (v < 0) {
+		o.push_back('-');
+		put_u(o, (uint64_t)(-v));
+	} else {
+		put_u(o, (uint64_t)v);
+	}
 }
 
 namespace {
@@ -115,17 +150,62 @@ struct RSub
 	uint32_t s1, s2, s3;
 };
 
-struct ContigState
+// one piece of a contig's _edited.fa record: a span of the (possibly modified) draft, or
+// of the record's own small text (header, inserted bases, newlines)
+struct Piece
+{
+	const char* p; // nullptr: `off` indexes ContigOut::text
+	size_t off;
+	size_t n;
+};
+
+// everything one contig contributes to the three output streams
+struct ContigOut
 {
 	std::vector<RNode> nodes;
 	std::vector<RSub> subs;
 	std::vector<char> seq; // private copy once a character changes
 	bool terminated = false;
+	std::vector<Piece> fa;
+	std::string text, tsv, vcf;
+	RenderStats st;
+	int rc = 0;
+	bool ready = false;
+
+	void reset()
+	{
+		nodes.clear();
+		subs.clear();
+		seq.clear();
+		terminated = false;
+		fa.clear();
+		text.clear();
+		tsv.clear();
+		vcf.clear();
+		st = RenderStats();
+		rc = 0;
+	}
+	void fa_text(const char* s, size_t n)
+	{
+		if (!fa.empty() && !fa.back().p && fa.back().off + fa.back().n == text.size()) {
+			fa.back().n += n;
+		} else {
+			Piece pc = { nullptr, text.size(), n };
+			fa.push_back(pc);
+		}
+		text.append(s, n);
+	}
+	void fa_char(char c) { fa_text(&c, 1); }
+	void fa_span(const char* s, size_t n)
+	{
+		Piece pc = { s, 0, n };
+		fa.push_back(pc);
+	}
 };
 
 // the substitution line of _variants.vcf (ntedit.cpp:986-1162)
 void
-write_vcf_substitution(FILE* vcf, const std::string& H, const RSub& s, const RenderOptions& opt, bool is_edit)
+write_vcf_substitution(std::string& vcf, const std::string& H, const RSub& s, const RenderOptions& opt, bool is_edit)
 {
 	std::string base(1, (char)s.sub);
 	std::string support = std::to_string(s.support);
@@ -208,31 +288,38 @@ write_vcf_substitution(FILE* vcf, const std::string& H, const RSub& s, const Ren
 			ids.push_back(H + ">" + D + pos1 + (char)toupper((unsigned char)best_alt_base));
 		}
 	}
-	fprintf(vcf, "%s\t%u\t.\t%c\t%s\t.\tPASS\tAD=%s", H.c_str(), s.pos + 1, s.draft, base.c_str(), support.c_str());
+	// "%s\t%u\t.\t%c\t%s\t.\tPASS\tAD=%s"
+	vcf += H;
+	vcf.push_back('\t');
+	put_u(vcf, (uint64_t)s.pos + 1);
+	vcf += "\t.\t";
+	vcf.push_back((char)s.draft);
+	vcf.push_back('\t');
+	vcf += base.c_str(); // (%s: an alternate base of 0 ends the string, as in the reference)
+	vcf += "\t.\tPASS\tAD=";
+	vcf += support;
 	for (const std::string& id : ids) {
 		put_annot(vcf, opt.annot, id);
 	}
-	fprintf(vcf, "\tGT\t%s\n", genotype);
+	vcf += "\tGT\t";
+	vcf += genotype;
+	vcf.push_back('\n');
 }
 
-// Writes one record the way writeEditsToFile walks the rope (ntedit.cpp:936-1212).
+// Renders one record the way writeEditsToFile walks the rope (ntedit.cpp:936-1212).
 void
-write_contig(
-    const char* hdr,
-    const char* seq,
-    const std::vector<RNode>& nodes,
-    const std::vector<RSub>& subs,
-    FILE* fa,
-    FILE* tsv,
-    RenderStats* st,
-    FILE* vcf,
-    const RenderOptions& opt)
+write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool want_tsv, bool want_vcf, const RenderOptions& opt)
 {
+	const std::vector<RNode>& nodes = o.nodes;
+	const std::vector<RSub>& subs = o.subs;
+	RenderStats* st = &o.st;
+	std::string& tsv = o.tsv;
+	std::string& vcf = o.vcf;
 	const std::string H(hdr);
-	if (fa) {
-		fputc('>', fa);
-		fputs(hdr, fa);
-		fputc('\n', fa);
+	if (want_fa) {
+		o.fa_char('>');
+		o.fa_text(H.data(), H.size());
+		o.fa_char('\n');
 	}
 	size_t qi = 0;
 	std::string ins;
@@ -245,15 +332,34 @@ write_contig(
 		if (cur.type == 0) {
 			if (!ins.empty()) {
 				unsigned char draft_char = (unsigned char)seq[cur.s_pos - ins.size()];
-				if (tsv) {
-					fprintf(tsv, "%s\t%u\t%c\t+%s\t%d\n", hdr, pos, draft_char, ins.c_str(), num_support);
+				if (want_tsv) {
+					// "%s\t%u\t%c\t+%s\t%d\n" (%s stops at an embedded NUL, like the reference's c_str())
+					tsv += H;
+					tsv.push_back('\t');
+					put_u(tsv, pos);
+					tsv.push_back('\t');
+					tsv.push_back((char)draft_char);
+					tsv += "\t+";
+					tsv += ins.c_str();
+					tsv.push_back('\t');
+					put_i(tsv, num_support);
+					tsv.push_back('\n');
 				}
-				if (vcf) {
+				if (want_vcf) {
 					// ntedit.cpp:954-977
 					const char D = (char)toupper(draft_char);
-					fprintf(vcf, "%s\t%u\t.\t%c\t%c%s\t.\tPASS\tAD=%d", hdr, pos, draft_char, draft_char, ins.c_str(), num_support);
+					vcf += H;
+					vcf.push_back('\t');
+					put_u(vcf, pos);
+					vcf += "\t.\t";
+					vcf.push_back((char)draft_char);
+					vcf.push_back('\t');
+					vcf.push_back((char)draft_char);
+					vcf += ins.c_str();
+					vcf += "\t.\tPASS\tAD=";
+					put_i(vcf, num_support);
 					put_annot(vcf, opt.annot, H + ">" + D + std::to_string(pos) + D + upper(ins.data(), ins.size()));
-					fputs("\tGT\t1/1\n", vcf);
+					vcf += "\tGT\t1/1\n";
 				}
 				st->insertions++;
 				ins.clear();
@@ -262,29 +368,46 @@ write_contig(
 			while (qi < subs.size() && subs[qi].pos <= cur.e_pos) {
 				const RSub& s = subs[qi];
 				const bool is_edit = !(opt.snv && s.draft == s.sub); // "snv_mode_no_edit" in the reference
-				if (vcf) {
+				if (want_vcf) {
 					write_vcf_substitution(vcf, H, s, opt, is_edit);
 				}
-				if (tsv && is_edit) {
-					fprintf(tsv, "%s\t%u\t%c\t%c\t%u", hdr, s.pos + 1, s.draft, s.sub, s.support);
+				if (want_tsv && is_edit) {
+					tsv += H;
+					tsv.push_back('\t');
+					put_u(tsv, (uint64_t)s.pos + 1);
+					tsv.push_back('\t');
+					tsv.push_back((char)s.draft);
+					tsv.push_back('\t');
+					tsv.push_back((char)s.sub);
+					tsv.push_back('\t');
+					put_u(tsv, s.support);
 					if (s.s1 > 0) {
-						fprintf(tsv, "\t%c\t%u", s.a1, s.s1);
+						tsv.push_back('\t');
+						tsv.push_back((char)s.a1);
+						tsv.push_back('\t');
+						put_u(tsv, s.s1);
 					}
 					if (s.s2 > 0) {
-						fprintf(tsv, "\t%c\t%u", s.a2, s.s2);
+						tsv.push_back('\t');
+						tsv.push_back((char)s.a2);
+						tsv.push_back('\t');
+						put_u(tsv, s.s2);
 					}
 					if (s.s3 > 0) {
-						fprintf(tsv, "\t%c\t%u", s.a3, s.s3);
+						tsv.push_back('\t');
+						tsv.push_back((char)s.a3);
+						tsv.push_back('\t');
+						put_u(tsv, s.s3);
 					}
-					fputc('\n', tsv);
+					tsv.push_back('\n');
 				}
 				if (is_edit) {
 					st->substitutions++;
 				}
 				qi++;
 			}
-			if (fa) {
-				fwrite(seq + cur.s_pos, 1, (size_t)cur.e_pos - cur.s_pos + 1, fa);
+			if (want_fa) {
+				o.fa_span(seq + cur.s_pos, (size_t)cur.e_pos - cur.s_pos + 1);
 			}
 			pos = cur.e_pos + 1;
 		} else if (cur.type == 1) {
@@ -292,36 +415,244 @@ write_contig(
 			if (num_support == -1) {
 				num_support = (int)cur.support;
 			}
-			if (fa) {
-				fputc(cur.c, fa);
+			if (want_fa) {
+				o.fa_char((char)cur.c);
 			}
 		}
 		ni++;
 		if (ni < nn) {
 			const RNode& nx = nodes[ni];
 			if (nx.type == 0 && nx.s_pos != pos) {
-				if (tsv) {
-					fprintf(tsv, "%s\t%u\t%c\t-", hdr, pos, seq[pos]);
-					fwrite(seq + pos, 1, (size_t)nx.s_pos - pos, tsv);
-					fprintf(tsv, "\t%u\n", nx.support);
+				if (want_tsv) {
+					// "%s\t%u\t%c\t-" + the deleted bases + "\t%u\n"
+					tsv += H;
+					tsv.push_back('\t');
+					put_u(tsv, pos);
+					tsv.push_back('\t');
+					tsv.push_back(seq[pos]);
+					tsv += "\t-";
+					tsv.append(seq + pos, (size_t)nx.s_pos - pos);
+					tsv.push_back('\t');
+					put_u(tsv, nx.support);
+					tsv.push_back('\n');
 				}
-				if (vcf && pos > 0) {
+				if (want_vcf && pos > 0) {
 					// ntedit.cpp:1184-1208
 					const size_t dl = (size_t)(nx.s_pos - pos) + 1;
-					fprintf(vcf, "%s\t%u\t.\t", hdr, pos);
-					fwrite(seq + pos - 1, 1, dl, vcf);
-					fprintf(vcf, "\t%c\t.\tPASS\tAD=%u", seq[pos - 1], nx.support);
+					vcf += H;
+					vcf.push_back('\t');
+					put_u(vcf, pos);
+					vcf += "\t.\t";
+					vcf.append(seq + pos - 1, dl);
+					vcf.push_back('\t');
+					vcf.push_back(seq[pos - 1]);
+					vcf += "\t.\tPASS\tAD=";
+					put_u(vcf, nx.support);
 					put_annot(vcf, opt.annot,
 					          H + ">" + upper(seq + pos - 1, dl) + std::to_string(pos) + (char)toupper((unsigned char)seq[pos - 1]));
-					fputs("\tGT\t1/1\n", vcf);
+					vcf += "\tGT\t1/1\n";
 				}
 				st->deletions++;
 			}
 		}
 	}
-	if (fa) {
-		fputc('\n', fa);
+	if (want_fa) {
+		o.fa_char('\n');
 	}
+}
+
+struct BatchView
+{
+	const Item* arena;
+	size_t arena_items;
+	const uint32_t* ev_first;
+	const char* bases;
+	const uint64_t* offsets;
+	const uint32_t* lens;
+	const char* const* names;
+	bool want_fa, want_tsv, want_vcf;
+	RenderOptions opt;
+};
+
+// events [ev, ev_end) of contig ci -> o
+void
+render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigOut& cs)
+{
+	cs.reset();
+	const char* seq = v.bases + v.offsets[ci];
+	const uint32_t len = v.lens[ci];
+	const Item* arena = v.arena;
+	const size_t arena_items = v.arena_items;
+	RNode root = { 0, 0, len ? len - 1 : 0, 0, 0 };
+	cs.nodes.push_back(root);
+	uint32_t cover = 0;
+	bool any = false;
+	for (; ev < ev_end; ev++) {
+		const uint32_t fc = v.ev_first[ev];
+		const Item& hdr = arena[(size_t)fc * nte::CHUNK_ITEMS + 1]; // (bounds checked by the caller)
+		const uint32_t start = hdr.w[1], cover_end = hdr.w[2];
+		if (start < cover) {
+			continue; // overtaken by an earlier event's serial run
+		}
+		cover = cover_end;
+		cs.st.events_applied++;
+		any = true;
+		// walk the chunk chain
+		bool first_node = true;
+		uint32_t chunk = fc;
+		bool first_chunk = true;
+		while (chunk != nte::NONE32) {
+			if ((size_t)(chunk + 1) * nte::CHUNK_ITEMS > arena_items) {
+				cs.rc = -1;
+				return;
+			}
+			const Item* c = arena + (size_t)chunk * nte::CHUNK_ITEMS;
+			uint32_t next = c[0].w[0], cnt = c[0].w[1];
+			if (cnt > nte::CHUNK_ITEMS) {
+				cs.rc = -3;
+				return;
+			}
+			for (uint32_t i = first_chunk ? 2 : 1; i < cnt; i++) {
+				const Item& it = c[i];
+				switch (it.w[0] & 0xFF) {
+				case nte::TAG_NODE: {
+					if (cs.terminated) {
+						break;
+					}
+					RNode n;
+					n.type = (int)(int8_t)((it.w[0] >> 8) & 0xFF);
+					n.c = (uint8_t)((it.w[0] >> 16) & 0xFF);
+					n.s_pos = it.w[1];
+					n.e_pos = it.w[2];
+					n.support = it.w[3];
+					if (first_node) {
+						// the event's rope starts with (its view of) the open node
+						// that currently ends the contig's rope
+						first_node = false;
+						RNode& open = cs.nodes.back();
+						if (n.type == 0 && n.s_pos == 0) {
+							n.s_pos = open.s_pos;
+							n.support = open.support;
+						}
+						open = n;
+						if (n.type == -1) {
+							cs.terminated = true;
+						}
+					} else {
+						cs.nodes.push_back(n);
+						if (n.type == -1) {
+							cs.terminated = true;
+						}
+					}
+					break;
+				}
+				case nte::TAG_SUB: {
+					RSub s;
+					s.draft = (uint8_t)((it.w[0] >> 8) & 0xFF);
+					s.sub = (uint8_t)((it.w[0] >> 16) & 0xFF);
+					s.support = (it.w[0] >> 24) & 0xFF;
+					s.pos = it.w[1];
+					s.a1 = (uint8_t)(it.w[2] & 0xFF);
+					s.s1 = (it.w[2] >> 8) & 0xFF;
+					s.a2 = (uint8_t)((it.w[2] >> 16) & 0xFF);
+					s.s2 = (it.w[2] >> 24) & 0xFF;
+					s.a3 = (uint8_t)(it.w[3] & 0xFF);
+					s.s3 = (it.w[3] >> 8) & 0xFF;
+					cs.subs.push_back(s);
+					break;
+				}
+				case nte::TAG_MOD: {
+					if (cs.seq.empty()) {
+						cs.seq.assign(seq, seq + len);
+					}
+					if (it.w[1] < len) {
+						cs.seq[it.w[1]] = (char)((it.w[0] >> 8) & 0xFF);
+					}
+					break;
+				}
+				default:
+					cs.rc = -4;
+					return;
+				}
+			}
+			first_chunk = false;
+			chunk = next;
+		}
+	}
+	const char* out_seq = cs.seq.empty() ? seq : cs.seq.data();
+	if (!any) {
+		// untouched contig: header + sequence + newline
+		if (v.want_fa) {
+			cs.fa_char('>');
+			cs.fa_text(v.names[ci], strlen(v.names[ci]));
+			cs.fa_char('\n');
+			cs.fa_span(seq, len);
+			cs.fa_char('\n');
+		}
+		return;
+	}
+	write_contig(v.names[ci], out_seq, cs, v.want_fa, v.want_tsv, v.want_vcf, v.opt);
+}
+
+int
+emit_contig(const ContigOut& o, FILE* fa, FILE* tsv, FILE* vcf, RenderStats* st)
+{
+	if (fa && !o.fa.empty()) {
+		// the record is a gather of draft spans: hand them to the kernel as they are instead
+		// of copying everything through the stream's buffer first
+		fflush(fa);
+		const int fd = fileno(fa);
+		std::vector<iovec> iov;
+		iov.reserve(o.fa.size() < 1024 ? o.fa.size() : 1024);
+		size_t i = 0;
+		while (i < o.fa.size()) {
+			iov.clear();
+			size_t want = 0;
+			while (i < o.fa.size() && iov.size() < 1024) {
+				const Piece& pc = o.fa[i++];
+				if (pc.n) {
+					iovec v;
+					v.iov_base = const_cast<char*>(pc.p ? pc.p : o.text.data() + pc.off);
+					v.iov_len = pc.n;
+					iov.push_back(v);
+					want += pc.n;
+				}
+			}
+			size_t first = 0;
+			while (want) {
+				const ssize_t w = writev(fd, iov.data() + first, (int)(iov.size() - first));
+				if (w < 0) {
+					if (errno == EINTR) {
+						continue;
+					}
+					return -5;
+				}
+				want -= (size_t)w;
+				size_t left = (size_t)w;
+				while (left && first < iov.size()) { // (a short write: resume inside the vector)
+					if (left >= iov[first].iov_len) {
+						left -= iov[first].iov_len;
+						first++;
+					} else {
+						iov[first].iov_base = (char*)iov[first].iov_base + left;
+						iov[first].iov_len -= left;
+						left = 0;
+					}
+				}
+			}
+		}
+	}
+	if (tsv && !o.tsv.empty()) {
+		fwrite(o.tsv.data(), 1, o.tsv.size(), tsv);
+	}
+	if (vcf && !o.vcf.empty()) {
+		fwrite(o.vcf.data(), 1, o.vcf.size(), vcf);
+	}
+	st->events_applied += o.st.events_applied;
+	st->substitutions += o.st.substitutions;
+	st->insertions += o.st.insertions;
+	st->deletions += o.st.deletions;
+	return 0;
 }
 
 } // namespace
@@ -369,136 +700,134 @@ render_batch(
     FILE* vcf,
     const RenderOptions* opt_in)
 {
-	const RenderOptions opt = opt_in ? *opt_in : RenderOptions();
 	RenderStats local;
 	RenderStats* st = stats ? stats : &local;
-	size_t ev = 0;
-	ContigState cs;
-	for (uint32_t ci = 0; ci < n_contigs; ci++) {
-		const char* seq = bases + offsets[ci];
-		const uint32_t len = lens[ci];
-		cs.nodes.clear();
-		cs.subs.clear();
-		cs.seq.clear();
-		cs.terminated = false;
-		RNode root = { 0, 0, len ? len - 1 : 0, 0, 0 };
-		cs.nodes.push_back(root);
-		uint32_t cover = 0;
-		bool any = false;
-		while (ev < n_events) {
-			uint32_t fc = ev_first[ev];
-			if ((size_t)fc * nte::CHUNK_ITEMS + 1 >= arena_items) {
-				return -1;
-			}
-			const Item& hdr = arena[(size_t)fc * nte::CHUNK_ITEMS + 1];
-			if (hdr.w[0] != ci) {
-				if (hdr.w[0] < ci) {
-					return -2; // events must arrive in contig order
-				}
-				break;
-			}
-			ev++;
-			const uint32_t start = hdr.w[1], cover_end = hdr.w[2];
-			if (start < cover) {
-				continue; // overtaken by an earlier event's serial run
-			}
-			cover = cover_end;
-			st->events_applied++;
-			any = true;
-			// walk the chunk chain
-			bool first_node = true;
-			uint32_t chunk = fc;
-			bool first_chunk = true;
-			while (chunk != nte::NONE32) {
-				if ((size_t)(chunk + 1) * nte::CHUNK_ITEMS > arena_items) {
+	BatchView v;
+	v.arena = arena;
+	v.arena_items = arena_items;
+	v.ev_first = ev_first;
+	v.bases = bases;
+	v.offsets = offsets;
+	v.lens = lens;
+	v.names = names;
+	v.want_fa = fa != nullptr;
+	v.want_tsv = tsv != nullptr;
+	v.want_vcf = vcf != nullptr;
+	v.opt = opt_in ? *opt_in : RenderOptions();
+
+	// events of every contig: [ev_begin[ci], ev_begin[ci + 1])
+	std::vector<size_t> ev_begin((size_t)n_contigs + 1, 0);
+	{
+		size_t ev = 0;
+		for (uint32_t ci = 0; ci < n_contigs; ci++) {
+			ev_begin[ci] = ev;
+			while (ev < n_events) {
+				const uint32_t fc = ev_first[ev];
+				if ((size_t)fc * nte::CHUNK_ITEMS + 1 >= arena_items) {
 					return -1;
 				}
-				const Item* c = arena + (size_t)chunk * nte::CHUNK_ITEMS;
-				uint32_t next = c[0].w[0], cnt = c[0].w[1];
-				if (cnt > nte::CHUNK_ITEMS) {
-					return -3;
+				const uint32_t c = arena[(size_t)fc * nte::CHUNK_ITEMS + 1].w[0];
+				if (c != ci) {
+					if (c < ci) {
+						return -2; // events must arrive in contig order
+					}
+					break;
 				}
-				for (uint32_t i = first_chunk ? 2 : 1; i < cnt; i++) {
-					const Item& it = c[i];
-					switch (it.w[0] & 0xFF) {
-					case nte::TAG_NODE: {
-						if (cs.terminated) {
-							break;
-						}
-						RNode n;
-						n.type = (int)(int8_t)((it.w[0] >> 8) & 0xFF);
-						n.c = (uint8_t)((it.w[0] >> 16) & 0xFF);
-						n.s_pos = it.w[1];
-						n.e_pos = it.w[2];
-						n.support = it.w[3];
-						if (first_node) {
-							// the event's rope starts with (its view of) the open node
-							// that currently ends the contig's rope
-							first_node = false;
-							RNode& open = cs.nodes.back();
-							if (n.type == 0 && n.s_pos == 0) {
-								n.s_pos = open.s_pos;
-								n.support = open.support;
-							}
-							open = n;
-							if (n.type == -1) {
-								cs.terminated = true;
-							}
-						} else {
-							cs.nodes.push_back(n);
-							if (n.type == -1) {
-								cs.terminated = true;
-							}
-						}
-						break;
-					}
-					case nte::TAG_SUB: {
-						RSub s;
-						s.draft = (uint8_t)((it.w[0] >> 8) & 0xFF);
-						s.sub = (uint8_t)((it.w[0] >> 16) & 0xFF);
-						s.support = (it.w[0] >> 24) & 0xFF;
-						s.pos = it.w[1];
-						s.a1 = (uint8_t)(it.w[2] & 0xFF);
-						s.s1 = (it.w[2] >> 8) & 0xFF;
-						s.a2 = (uint8_t)((it.w[2] >> 16) & 0xFF);
-						s.s2 = (it.w[2] >> 24) & 0xFF;
-						s.a3 = (uint8_t)(it.w[3] & 0xFF);
-						s.s3 = (it.w[3] >> 8) & 0xFF;
-						cs.subs.push_back(s);
-						break;
-					}
-					case nte::TAG_MOD: {
-						if (cs.seq.empty()) {
-							cs.seq.assign(seq, seq + len);
-						}
-						if (it.w[1] < len) {
-							cs.seq[it.w[1]] = (char)((it.w[0] >> 8) & 0xFF);
-						}
-						break;
-					}
-					default:
-						return -4;
-					}
-				}
-				first_chunk = false;
-				chunk = next;
+				ev++;
 			}
 		}
-		const char* out_seq = cs.seq.empty() ? seq : cs.seq.data();
-		if (!any) {
-			// untouched contig: header + sequence + newline
-			if (fa) {
-				fputc('>', fa);
-				fputs(names[ci], fa);
-				fputc('\n', fa);
-				fwrite(seq, 1, len, fa);
-				fputc('\n', fa);
-			}
-			continue;
-		}
-		write_contig(names[ci], out_seq, cs.nodes, cs.subs, fa, tsv, st, vcf, opt);
+		ev_begin[n_contigs] = ev;
 	}
-	return 0;
+
+	unsigned T = v.opt.threads;
+	if (T == 0) {
+		T = std::thread::hardware_concurrency();
+		if (T > 8) {
+			T = 8;
+		}
+	}
+	if (T > n_contigs) {
+		T = n_contigs;
+	}
+	if (T <= 1) {
+		ContigOut o;
+		for (uint32_t ci = 0; ci < n_contigs; ci++) {
+			render_contig(v, ci, ev_begin[ci], ev_begin[ci + 1], o);
+			if (o.rc) {
+				return o.rc;
+			}
+			if (int e = emit_contig(o, fa, tsv, vcf, st)) {
+				return e;
+			}
+		}
+		return 0;
+	}
+
+	// workers render contigs (claimed in input order) into a ring of slots; this thread
+	// writes slot after slot, in input order
+	const uint32_t W = 2 * T + 2;
+	std::vector<ContigOut> slots(W);
+	std::atomic<uint32_t> next_ci(0);
+	std::mutex mu;
+	std::condition_variable cv_ready, cv_free;
+	uint32_t written = 0;
+	bool abort = false;
+	auto worker = [&]() {
+		for (;;) {
+			const uint32_t ci = next_ci.fetch_add(1);
+			if (ci >= n_contigs) {
+				return;
+			}
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv_free.wait(lk, [&]() { return abort || ci < written + W; });
+				if (abort) {
+					return;
+				}
+			}
+			ContigOut& o = slots[ci % W];
+			render_contig(v, ci, ev_begin[ci], ev_begin[ci + 1], o);
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				o.ready = true;
+			}
+			cv_ready.notify_all();
+		}
+	};
+	std::vector<std::thread> pool;
+	for (unsigned t = 0; t < T; t++) {
+		pool.emplace_back(worker);
+	}
+	int rc = 0;
+	for (uint32_t ci = 0; ci < n_contigs; ci++) {
+		ContigOut& o = slots[ci % W];
+		{
+			std::unique_lock<std::mutex> lk(mu);
+			cv_ready.wait(lk, [&]() { return o.ready; });
+		}
+		if (o.rc) {
+			rc = o.rc;
+			break;
+		}
+		if ((rc = emit_contig(o, fa, tsv, vcf, st))) {
+			break;
+		}
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			o.ready = false;
+			written = ci + 1;
+		}
+		cv_free.notify_all();
+	}
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		abort = true; // (no-op after a complete run: every worker has left its loop)
+	}
+	cv_free.notify_all();
+	for (std::thread& t : pool) {
+		t.join();
+	}
+	return rc;
 }
 
 } // namespace nte_host

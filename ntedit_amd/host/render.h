@@ -28,6 +28,7 @@ struct RenderOptions
 {
 	bool snv = false;               // -s 1: "no edit" substitution records go to the VCF only
 	const Annotations* annot = nullptr;
+	unsigned threads = 0;           // contigs rendered concurrently (0 = up to 8, 1 = in the calling thread)
 };
 
 // arena:    host copy of the chunk arena

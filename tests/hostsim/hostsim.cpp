@@ -215,6 +215,9 @@ hostsim_polish(
 		nte_host::write_vcf_header(vcf, "draft");
 	}
 	nte_host::RenderOptions ropt;
+	if (const char* rt = getenv("HOSTSIM_RENDER_THREADS")) {
+		ropt.threads = (unsigned)atoi(rt);
+	}
 	ropt.snv = hp->snv != 0;
 	nte_host::Annotations* ann = annot_path ? nte_host::annotations_load(annot_path) : nullptr;
 	ropt.annot = ann;
@@ -251,4 +254,37 @@ hostsim_polish(
 		*n_applied_out = st.events_applied;
 	}
 	return rc;
+}
+
+
+// TEST-ONLY: dumps what the host FASTA/FASTQ reader (ntedit_amd/host/fasta.cpp) yields for a file:
+// "<header length> <sequence length>\n<header>\n<sequence>\n" per record
+#include "../../ntedit_amd/host/fasta.h"
+extern "C" int
+hostsim_fasta_dump(const char* in_path, const char* out_path)
+{
+	nte_host::FastaReader r(in_path);
+	if (!r.ok()) {
+		return -1;
+	}
+	FILE* o = fopen(out_path, "wb");
+	if (!o) {
+		return -2;
+	}
+	std::string hdr, blob;
+	int n = 0;
+	for (;;) {
+		const size_t before = blob.size();
+		if (!r.next(hdr, blob)) {
+			break;
+		}
+		fprintf(o, "%zu %zu\n", hdr.size(), blob.size() - before);
+		fwrite(hdr.data(), 1, hdr.size(), o);
+		fputc('\n', o);
+		fwrite(blob.data() + before, 1, blob.size() - before, o);
+		fputc('\n', o);
+		n++;
+	}
+	fclose(o);
+	return n;
 }

@@ -38,12 +38,13 @@ def main():
     out = {"bases": int(bases), "draft_bytes": os.path.getsize(draft)}
     t0 = time.perf_counter()
     r = subprocess.run([os.path.join(ROOT, "ntedit_amd", "ntedit"), "-f", draft, "-r", bf, "-b",
-                        os.path.join(work, "gpu"), "--report", "--batch-bases", str(1 << 32)], capture_output=True, text=True)
+                        os.path.join(work, "gpu"), "--report"], capture_output=True, text=True)
     out["cli_wall_s"] = round(time.perf_counter() - t0, 3)
     assert r.returncode == 0, r.stderr
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     out["cli_polish_region_s"] = rep["seconds"]
     out["cli_gpu_ms"] = rep["gpu_ms"]
+    out["cli_stage_seconds"] = {"read": rep["read_s"], "polish_call": rep["polish_call_s"], "write": rep["write_s"]}
     out["cli_mbases_per_s_polish_region"] = round(rep["bases"] / rep["seconds"] / 1e6, 1)
     out["events_applied"] = rep["events_applied"]
     # CPU oracle, same files, on the first ~30 Mbases (whole-file run would take minutes)

@@ -110,6 +110,9 @@ void* ntedit_hip_filter_device_ptr(const ntedit_hip_ctx* ctx, int slot);
  * download / save it. */
 int ntedit_hip_filter_alloc(ntedit_hip_ctx* ctx, int slot, uint64_t nbytes, uint32_t hash_num, uint32_t k);
 int ntedit_hip_filter_insert(ntedit_hip_ctx* ctx, int slot, const char* bases, uint64_t n, int on_device);
+/* occupied = set bits (plain) / non-zero counters (counting), slots = bits / counters:
+ * btllib's get_fpr() is (occupied / slots)^hash_num (printed at ntedit_make_genome_bf.cpp:159) */
+int ntedit_hip_filter_occupancy(ntedit_hip_ctx* ctx, int slot, uint64_t* occupied, uint64_t* slots);
 int ntedit_hip_filter_download(const ntedit_hip_ctx* ctx, int slot, uint8_t* bits);
 int ntedit_hip_filter_save_file(const ntedit_hip_ctx* ctx, int slot, const char* path);
 

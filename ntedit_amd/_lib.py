@@ -66,7 +66,7 @@ EXPORTS = [
     "ntedit_hip_result_free", "ntedit_hip_result_stats", "ntedit_hip_write_outputs",
     "ntedit_hip_write_tsv_header", "ntedit_hip_last_kernel_ms", "ntedit_hip_gather_bench",
     "ntedit_hip_annot_load", "ntedit_hip_annot_free", "ntedit_hip_write_vcf_header", "ntedit_hip_write_outputs_vcf",
-    "ntedit_hip_set_host_threads",
+    "ntedit_hip_set_host_threads", "ntedit_hip_filter_occupancy",
 ]
 
 _lib = None
@@ -118,6 +118,7 @@ def load():
     lib.ntedit_hip_write_vcf_header.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     lib.ntedit_hip_write_outputs_vcf.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_char_p), u32,
                                                  ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ci, ci, vp]
+    lib.ntedit_hip_filter_occupancy.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.ntedit_hip_set_host_threads.argtypes = [ctypes.c_uint]
     lib.ntedit_hip_set_host_threads.restype = None
     lib.ntedit_hip_last_kernel_ms.argtypes = [vp]

@@ -883,6 +883,34 @@ ntedit_hip_filter_insert(ntedit_hip_ctx* c, int slot, const char* bases, uint64_
 }
 
 int
+ntedit_hip_filter_occupancy(ntedit_hip_ctx* c, int slot, uint64_t* occupied, uint64_t* slots)
+{
+	if (!c || slot < 0 || slot > 1 || !c->filt[slot].set || !occupied) {
+		return fail(c, NTEDIT_E_ARG, "filter_occupancy: bad argument");
+	}
+	HIP_TRY(c, hipSetDevice(c->device));
+	const DevFilter& f = c->filt[slot];
+	int rc = ensure(c, c->counters, 256);
+	if (rc) {
+		return rc;
+	}
+	unsigned long long* d_total = (unsigned long long*)c->counters.p;
+	HIP_TRY(c, hipMemsetAsync(d_total, 0, 8, c->stream));
+	const u64 n_words = f.nbytes / 8; // (filters are whole 64-bit words)
+	hipLaunchKernelGGL(k_popcount, dim3((unsigned)(c->cu_count * 8)), dim3(256), 0, c->stream, (const u64*)f.data, n_words,
+	                   f.counting ? 1 : 0, d_total);
+	HIP_TRY(c, hipGetLastError());
+	unsigned long long h = 0;
+	HIP_TRY(c, hipMemcpyAsync(&h, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	*occupied = h;
+	if (slots) {
+		*slots = f.counting ? f.nbytes : f.nbytes * 8;
+	}
+	return 0;
+}
+
+int
 ntedit_hip_filter_download(const ntedit_hip_ctx* c, int slot, uint8_t* bits)
 {
 	if (!c || slot < 0 || slot > 1 || !c->filt[slot].set || !bits) {

@@ -8,6 +8,7 @@
 //   k_count_starts / k_scan_counts / k_write_starts
 //                   turn the absent bitmap into the ordered list of event starts
 //   k_machine       one thread per event: steps 2-5 + makeEdit (nte_machine.h)
+//   k_popcount      occupancy of a filter (for get_fpr)
 //   k_gather        random 1-byte gather micro-benchmark (roofline denominator)
 //
 // Roofline: all of this is integer hashing + random 1-byte gathers from a
@@ -818,6 +819,34 @@ k_write_starts(
 // (k_machine lives in its own translation units, nte_machine_thread.hip / nte_machine_wave.hip:
 // the fully inlined state machine is by far the largest kernel and the two variants compile in
 // parallel; interface in nte_machine_launch.h)
+
+// ---------------------------------------------------------------- k_popcount
+// set bits of a filter (plain) / non-zero counters (counting): the occupancy behind
+// btllib's get_fpr() = (occupied / slots)^hash_num, printed by ntedit-make-genome-bf
+// (src/ntedit_make_genome_bf.cpp:159).  Streaming read, one atomic per wavefront.
+__global__ __launch_bounds__(256) void
+k_popcount(const u64* __restrict__ words, u64 n_words, int counting, unsigned long long* __restrict__ total)
+{
+	u64 acc = 0;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (u64)gridDim.x * blockDim.x) {
+		const u64 w = words[i];
+		if (counting) {
+			// bytes that are not zero: fold every byte's bits onto its lowest bit
+			u64 t = w | (w >> 4);
+			t |= t >> 2;
+			t |= t >> 1;
+			acc += (u64)__popcll(t & 0x0101010101010101ULL);
+		} else {
+			acc += (u64)__popcll(w);
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		acc += __shfl_down(acc, off, 64);
+	}
+	if ((threadIdx.x & 63) == 0 && acc) {
+		atomicAdd(total, (unsigned long long)acc);
+	}
+}
 
 // ------------------------------------------------------------------ k_gather
 // Uniform random 1-byte gathers, 12 independent loads in flight per lane

@@ -138,6 +138,13 @@ class Polisher:
                     "filter_download")
         return out
 
+    def filter_occupancy(self, slot=PRIMARY):
+        """(occupied, slots): set bits / non-zero counters and the filter's size in slots"""
+        occ, slots = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self._lib.ntedit_hip_filter_occupancy(self._h, slot, ctypes.byref(occ), ctypes.byref(slots)),
+                    "filter_occupancy")
+        return occ.value, slots.value
+
     def filter_save_file(self, path, slot=PRIMARY):
         self._check(self._lib.ntedit_hip_filter_save_file(self._h, slot, path.encode()), "filter_save_file")
 

@@ -368,3 +368,44 @@ def test_full_size_properties(tmp_path, oracle_build):
         assert sum(len(v) for v in exp_tsv.values()) > 100
     finally:
         pol.close()
+
+
+def test_make_genome_bf_cli(tmp_path, oracle_build):
+    """ntedit-make-genome-bf: command line and console lines of the reference tool
+    (src/ntedit_make_genome_bf.cpp), filter file byte-identical to the oracle's mkbf"""
+    import math
+    import subprocess
+    rng = np.random.default_rng(21)
+    g1 = [(b"a x", H.random_genome(rng, 120000)), (b"tiny", b"ACGTACGT"), (b"b", H.random_genome(rng, 3000).lower())]
+    g2 = [(b"c", H.random_genome(rng, 40000)[:20000] + b"NNNNNNNNNN" + H.random_genome(rng, 20000))]
+    H.write_fasta(str(tmp_path / "g1.fa"), g1, width=60)
+    H.write_fasta(str(tmp_path / "g2.fa"), g2)
+    tool = os.path.join(H.ROOT, "ntedit_amd", "ntedit-make-genome-bf")
+    # explicit size
+    out = str(tmp_path / "t.bf")
+    r = subprocess.run([tool, "--genome", str(tmp_path / "g1.fa"), str(tmp_path / "g2.fa"), "-k", "25", "--hashes", "4",
+                        "--bf", "100003", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "BF size (bytes): 100003" in r.stdout
+    H.mkbf([str(tmp_path / "g1.fa"), str(tmp_path / "g2.fa")], str(tmp_path / "o.bf"), k=25, hashes=4, nbytes=100003)
+    got, want = H.load_bf(out), H.load_bf(str(tmp_path / "o.bf"))
+    assert got["k"] == 25 and got["hash_num"] == 4
+    assert np.array_equal(got["data"], want["data"])
+    assert open(out, "rb").read() == open(str(tmp_path / "o.bf"), "rb").read()
+    occ = int(np.unpackbits(want["data"]).sum())
+    fpr = (occ / (want["data"].size * 8)) ** 4
+    line = [l for l in r.stdout.splitlines() if l.startswith("Bloom filter FPR: ")][0]
+    assert abs(float(line.split(": ")[1]) - fpr) <= 1e-5 * fpr + 1e-12
+    # size from the genome length (ntedit_make_genome_bf.cpp:41-47,131-135)
+    r = subprocess.run([tool, "--genome", str(tmp_path / "g1.fa"), "-k", "31", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    n = sum(len(s) for _, s in g1)
+    assert "Genome size (bp): %d" % n in r.stdout
+    rr = -3.0 / math.log(1.0 - math.exp(math.log(0.01) / 3.0))
+    size = int(math.ceil(n * rr) / 8)
+    assert "BF size (bytes): %d" % size in r.stdout
+    H.mkbf([str(tmp_path / "g1.fa")], str(tmp_path / "o.bf"), k=31, hashes=3, nbytes=size)
+    assert np.array_equal(H.load_bf(out)["data"], H.load_bf(str(tmp_path / "o.bf"))["data"])
+    # usage errors
+    assert subprocess.run([tool, "-k", "25"], capture_output=True).returncode == 1
+    assert subprocess.run([tool, "--genome", str(tmp_path / "g1.fa")], capture_output=True).returncode == 1

@@ -61,6 +61,8 @@ typedef struct ntedit_hip_params
 	uint32_t start_grid;       /* extra event start every N positions in an absent run (power of 2) */
 	uint32_t node_window;      /* rope nodes kept live per event thread */
 	uint32_t screen_mode;      /* 0 auto, 1 direct gather kernel, 2 L2-partitioned (binned) pipeline */
+	uint32_t event_budget;     /* positions a speculative event may walk before it is parked and, if it
+	                              turns out to be applied, re-run to completion (0 = default 2048) */
 } ntedit_hip_params;
 
 /* defaults of ntedit.cpp:99-133 */

@@ -34,6 +34,7 @@ class Params(ctypes.Structure):
         ("start_grid", ctypes.c_uint32),
         ("node_window", ctypes.c_uint32),
         ("screen_mode", ctypes.c_uint32),
+        ("event_budget", ctypes.c_uint32),
     ]
 
 

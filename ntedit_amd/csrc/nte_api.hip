@@ -9,6 +9,7 @@
 #include "../host/bfio.h"
 #include "../host/params.h"
 #include "../host/render.h"
+#include "../host/resolve.h"
 
 #include <atomic>
 #include <cstdarg>
@@ -1173,6 +1174,31 @@ ntedit_hip_polish_batch(
 		u32 status = 0;
 		float ms_extract = 0.f, ms_machine = 0.f;
 		bool first_b = true;
+		MachineArgs keep_a; // the last chunk's launch arguments (re-runs of parked events)
+		memset(&keep_a, 0, sizeof keep_a);
+		// the wavefront-per-event kernel over a list of events of the current chunk
+		auto launch_wave_pass = [&](MachineArgs a, const u32* list, u32 count) {
+			a.defer = 0;
+			a.ev_list = list;
+			a.n_events = count;
+			const u64 per_block = (u64)MACHINE_TPB / (u64)machine_wave_group();
+			const u64 want2 = ((u64)count + per_block - 1) / per_block;
+			const u64 cap2 = (u64)c->cu_count * 8;
+			const u64 b2 = want2 < cap2 ? want2 : cap2;
+			// the wave kernel runs few events per block: window and workspace both fit in LDS
+			size_t dyn2 = a.win_in_lds ? (size_t)a.win_bytes * per_block : 0;
+			const u64 Wn = a.p.node_window;
+			const u64 w16 = (Wn + 15) & ~15ull;
+			const u64 slab = Wn * 16 + w16 * 4 + w16 * 2 + w16 + w16;
+			const u64 win_area = ((u64)a.win_bytes * per_block + 15) & ~15ull;
+			if (win_area + slab * per_block <= 40 * 1024 && !getenv("NTEDIT_HIP_NO_LDS_WS")) {
+				a.win_in_lds = 1;
+				a.lds_ws_off = (u32)win_area;
+				a.lds_slab = (u32)slab;
+				dyn2 = (size_t)(win_area + slab * per_block);
+			}
+			launch_k_machine_wave((unsigned)b2, dyn2, sB, a);
+		};
 		for (size_t j = 0; j < n_ch && status == 0; j++) {
 			const Chunk& ch = chunks[j];
 			HIP_TRY(c, hipStreamWaitEvent(sB, c->chunk_ev[2 * j + 1], 0));
@@ -1282,6 +1308,10 @@ ntedit_hip_polish_batch(
 			a.ev_list = nullptr;
 			a.deferred = (u32*)c->deferred.p;
 			a.n_deferred = d_ndef;
+			a.n_unfinished = (u32*)((char*)c->counters.p + 52);
+			if (n_ch != 1) {
+				a.p.event_budget = 0; // (parked events are re-run per batch: single-chunk batches only)
+			}
 			HIP_TRY(c, hipMemsetAsync(d_ndef, 0, 4, sB));
 			HIP_TRY(c, hipEventRecord(c->ev[3], sB));
 			// pass 1: every event, indel sweeps postponed
@@ -1308,33 +1338,14 @@ ntedit_hip_polish_batch(
 			}
 			if (n_def > 0 && status == 0) {
 				// pass 2: one wavefront per event that needs an indel sweep
-				a.defer = 0;
-				a.ev_list = (const u32*)c->deferred.p;
-				a.n_events = n_def;
-				const u64 per_block = (u64)MACHINE_TPB / (u64)machine_wave_group();
-				const u64 want2 = ((u64)n_def + per_block - 1) / per_block;
-				const u64 cap2 = (u64)c->cu_count * 8;
-				const u64 b2 = want2 < cap2 ? want2 : cap2;
-				// the wave kernel runs few events per block: window and workspace both fit in LDS
-				size_t dyn2 = a.win_in_lds ? (size_t)a.win_bytes * per_block : 0;
-				{
-					const u64 Wn = c->dp.node_window;
-					const u64 w16 = (Wn + 15) & ~15ull;
-					const u64 slab = Wn * 16 + w16 * 4 + w16 * 2 + w16 + w16;
-					const u64 win_area = ((u64)a.win_bytes * per_block + 15) & ~15ull;
-					if (win_area + slab * per_block <= 40 * 1024 && !getenv("NTEDIT_HIP_NO_LDS_WS")) {
-						a.win_in_lds = 1;
-						a.lds_ws_off = (u32)win_area;
-						a.lds_slab = (u32)slab;
-						dyn2 = (size_t)(win_area + slab * per_block);
-					}
-				}
+				MachineArgs a2 = a;
 				if (const char* dbg = getenv("NTEDIT_HIP_PASS2_DEBUG")) {
-					a.p.debug_stop = (u32)atoi(dbg); // timing ablations; results are NOT valid
+					a2.p.debug_stop = (u32)atoi(dbg); // timing ablations; results are NOT valid
 				}
-				launch_k_machine_wave((unsigned)b2, dyn2, sB, a);
+				launch_wave_pass(a2, (const u32*)c->deferred.p, n_def);
 				HIP_TRY(c, hipGetLastError());
 			}
+			keep_a = a;
 			HIP_TRY(c, hipEventRecord(c->ev[4], sB));
 			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
 			HIP_TRY(c, hipStreamSynchronize(sB));
@@ -1393,6 +1404,70 @@ ntedit_hip_polish_batch(
 			if (ev_total) {
 				HIP_TRY(c, hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));
 			}
+			HIP_TRY(c, hipStreamSynchronize(sB));
+			// Events parked by the budget: decide, in serial order, which of them are applied, re-run
+			// exactly those to completion, carry on behind them (host/resolve.h).  Nothing to do in
+			// the ordinary case.
+			u32 n_unfinished = 0;
+			HIP_TRY(c, hipMemcpy(&n_unfinished, (char*)c->counters.p + 52, 4, hipMemcpyDeviceToHost));
+			bool redo = false;
+			if (n_unfinished && n_ch == 1) {
+				nte_host::Resolver rs((const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p, ev_total);
+				std::vector<u32> rerun;
+				if (!rs.start(rerun)) {
+					return bail(fail(c, NTEDIT_E_DEVICE, "malformed event records"));
+				}
+				u64 have_chunks = used_chunks;
+				unsigned rounds = 0;
+				while (!rerun.empty()) {
+					HIP_TRY(c, hipMemcpyAsync(c->deferred.p, rerun.data(), rerun.size() * 4, hipMemcpyHostToDevice, sB));
+					MachineArgs ra = keep_a;
+					ra.p.event_budget = 0;
+					launch_wave_pass(ra, (const u32*)c->deferred.p, (u32)rerun.size());
+					HIP_TRY(c, hipGetLastError());
+					u32 t2[4] = { 0, 0, 0, 0 };
+					HIP_TRY(c, hipMemcpyAsync(t2, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+					HIP_TRY(c, hipStreamSynchronize(sB));
+					if (t2[2]) {
+						status = t2[2];
+						redo = true;
+						break;
+					}
+					const u64 now_chunks = t2[0] < arena_chunks ? t2[0] : arena_chunks;
+					const size_t need = (size_t)now_chunks * CHUNK_ITEMS * sizeof(Item) + 16;
+					if (r->arena_buf.cap < need) {
+						PinBuf bigger;
+						if ((rc = pin_take(c, need + need / 2, &bigger))) {
+							return bail(rc);
+						}
+						memcpy(bigger.p, r->arena_buf.p, (size_t)have_chunks * CHUNK_ITEMS * sizeof(Item));
+						pin_give(c, r->arena_buf);
+						r->arena_buf = bigger;
+					}
+					if (now_chunks > have_chunks) {
+						const size_t off = (size_t)have_chunks * CHUNK_ITEMS * sizeof(Item);
+						HIP_TRY(c, hipMemcpyAsync((char*)r->arena_buf.p + off, (char*)c->arena.p + off,
+						                          (size_t)(now_chunks - have_chunks) * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sB));
+					}
+					HIP_TRY(c, hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));
+					HIP_TRY(c, hipStreamSynchronize(sB));
+					have_chunks = now_chunks;
+					r->arena_items = (size_t)now_chunks * CHUNK_ITEMS;
+					rs.rebind((const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p);
+					rerun.clear();
+					if (!rs.resume(rerun) || ++rounds > 10000000u) {
+						return bail(fail(c, NTEDIT_E_DEVICE, "parked events could not be resolved"));
+					}
+				}
+				if (getenv("NTEDIT_HIP_DEBUG")) {
+					fprintf(stderr, "[ntedit_hip] %u events parked by the budget, %u re-run round(s)\n", n_unfinished, rounds);
+				}
+			}
+			if (redo) {
+				// a re-run ran out of arena / rope window: the whole batch again, with more room
+				pin_give(c, r->arena_buf);
+				pin_give(c, r->first_buf);
+			} else {
 			HIP_TRY(c, hipEventRecord(c->ev[4], sB));
 			HIP_TRY(c, hipStreamSynchronize(sB));
 			// keep the events that produced output, in position order (compacted in place)
@@ -1420,6 +1495,7 @@ ntedit_hip_polish_batch(
 			HIP_TRY(c, hipEventElapsedTime(&r->st.ms_total, c->ev[0], c->ev[4]));
 			c->last_ms = ms_screen;
 			break;
+			}
 		}
 		if (attempt >= 4) {
 			return bail(fail(c, NTEDIT_E_OVERFLOW, "event machine ran out of room (status %u)", status));

@@ -317,6 +317,7 @@ struct DevParams
 	u32 thr_missing, thr_edit, thr_edit_del;
 	u32 start_grid;    // extra event start every start_grid positions inside an absent run
 	u32 node_window;   // live rope nodes kept per event thread
+	u32 event_budget;  // positions an event may walk before it is parked as EV_UNFINISHED (0 = no limit)
 	u32 debug_stop;    // timing ablations only (NTEDIT_HIP_MACHINE_DEBUG): 1 seed, 2 step 2, 4 first position
 	u32 counting;      // primary filter is a counting filter
 	u32 snv;           // -s 1: every position is re-assessed (ntedit.cpp:1806,1865)
@@ -438,7 +439,9 @@ enum EventFlags : u32
 	EV_TERMINAL = 1,  // ran to the end of the contig
 	EV_OVERFLOW = 2,  // ran out of node window: results invalid (retry with a larger window)
 	EV_ARENA_FULL = 4, // output arena exhausted: results invalid (retry with a larger arena)
-	EV_DEFERRED = 8    // needs an indel sweep and the launch asked to postpone those (pass 1)
+	EV_DEFERRED = 8,   // needs an indel sweep and the launch asked to postpone those (pass 1)
+	EV_UNFINISHED = 16 // walked more positions than the launch's budget: what it emitted is void, its
+	                   // cover_end is the contig end; re-run without a budget if it turns out to be applied
 };
 
 struct Item

@@ -2075,9 +2075,18 @@ struct Machine
 			return;
 		}
 		bool first = true;
+		u32 steps = 0;
 		NTE_PROF_DECL;
 		while (true) {
 			NTE_PROF(first ? 0 : 5); // 0 = seeding, 5 = loop overhead
+			if (p.event_budget && ++steps > p.event_budget && cur_chunk != NONE32) {
+				// A run that does not come back to a clean state for this long is (almost
+				// always) one the serial order will discard: park it.  The host re-runs it
+				// without a budget if it turns out to be applied.
+				flags |= EV_UNFINISHED;
+				cover_end = e.len;
+				break;
+			}
 			if ((u64)h_seq_i + p.k - 1 >= e.len) {
 				flags |= EV_TERMINAL;
 				cover_end = e.len;
@@ -2159,7 +2168,7 @@ struct Machine
 		NTE_PROF(5);
 
 		// stream out what is left of the rope (only if an indel touched it)
-		if (rope_touched && !(flags & EV_DEFERRED)) {
+		if (rope_touched && !(flags & (EV_DEFERRED | EV_UNFINISHED))) {
 			for (u32 i = nbase; i < nsize; i++) {
 				Node n = nget(i);
 				if (n.type == -1) {

@@ -45,6 +45,7 @@ struct MachineArgs
 	const u32* ev_list; // nullptr = all events 0..n_events-1
 	u32* deferred;
 	u32* n_deferred;
+	u32* n_unfinished; // events parked by the budget (p.event_budget) in this launch
 };
 
 constexpr int MACHINE_TPB = 256;

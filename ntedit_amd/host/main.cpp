@@ -68,7 +68,9 @@ enum
 	OPT_GPU,
 	OPT_BATCH,
 	OPT_SHARD,
-	OPT_REPORT
+	OPT_REPORT,
+	OPT_START_GRID,
+	OPT_EVENT_BUDGET
 };
 static const struct option longopts[] = {
 	{ "threads", required_argument, nullptr, 't' },
@@ -95,6 +97,8 @@ static const struct option longopts[] = {
 	{ "maximum_kmer_coverage", required_argument, nullptr, 'q' },
 	{ "gpu", required_argument, nullptr, OPT_GPU },
 	{ "batch-bases", required_argument, nullptr, OPT_BATCH },
+	{ "start-grid", required_argument, nullptr, OPT_START_GRID },     // tuning / tests: ntedit_hip_params.start_grid
+	{ "event-budget", required_argument, nullptr, OPT_EVENT_BUDGET }, // tuning / tests: ntedit_hip_params.event_budget
 	{ "shard", required_argument, nullptr, OPT_SHARD },
 	{ "report", no_argument, nullptr, OPT_REPORT },
 	{ "help", no_argument, nullptr, OPT_HELP },
@@ -269,6 +273,12 @@ main(int argc, char** argv)
 			break;
 		case OPT_BATCH:
 			parse(c, optarg, batch_bases);
+			break;
+		case OPT_START_GRID:
+			parse(c, optarg, p.start_grid);
+			break;
+		case OPT_EVENT_BUDGET:
+			parse(c, optarg, p.event_budget);
 			break;
 		case OPT_SHARD:
 			if (sscanf(optarg, "%u/%u", &shard_i, &shard_n) != 2 || shard_n == 0 || shard_i >= shard_n) {

@@ -140,6 +140,13 @@ make_dev_params(
 		w = 4 * k + 64;
 	}
 	d.node_window = w;
+	// speculative events are cut off after this many positions; far above any realistic chain of edits,
+	// and always beyond the next forced event start
+	uint32_t budget = hp.event_budget ? hp.event_budget : 2048;
+	if (budget < 2 * g) {
+		budget = 2 * g;
+	}
+	d.event_budget = budget;
 	for (uint32_t i = 0; i < nte::MAX_HASHES; i++) {
 		d.mul[i] = (uint64_t)i ^ ((uint64_t)k * nte::MULTISEED);
 	}

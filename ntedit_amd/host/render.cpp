@@ -331,7 +331,9 @@ write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool 
 		const RNode& cur = nodes[ni];
 		if (cur.type == 0) {
 			if (!ins.empty()) {
-				unsigned char draft_char = (unsigned char)seq[cur.s_pos - ins.size()];
+				// (U4, oracle/ntedit_oracle.c) more inserted bases than bases in front of them: the
+				// reference's .at() throws there; the row gets 'N'
+				unsigned char draft_char = cur.s_pos >= ins.size() ? (unsigned char)seq[cur.s_pos - ins.size()] : (unsigned char)'N';
 				if (want_tsv) {
 					// "%s\t%u\t%c\t+%s\t%d\n" (%s stops at an embedded NUL, like the reference's c_str())
 					tsv += H;
@@ -493,6 +495,10 @@ render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigO
 		const uint32_t start = hdr.w[1], cover_end = hdr.w[2];
 		if (start < cover) {
 			continue; // overtaken by an earlier event's serial run
+		}
+		if (hdr.w[3] & nte::EV_UNFINISHED) {
+			cs.rc = -6; // a parked event must have been re-run before it can be applied
+			return;
 		}
 		cover = cover_end;
 		cs.st.events_applied++;

@@ -14,6 +14,10 @@
  *        behaviour on IUPAC input is unknown here; we define the seed hash as
  *        the XOR of per-character SEED_TAB terms (identical for ACGT input and
  *        consistent with the rolling update).
+ *   (U4) writeEditsToFile reads contigSeq.at(s_pos - insertion length) for an insertion
+ *        row (ntedit.cpp:957); when insertions accumulated to more bases than lie in
+ *        front of them that index wraps and .at() throws (the reference terminates).
+ *        Here the row is written with 'N' as its draft base.
  */
 #include "ntedit_oracle.h"
 
@@ -1744,7 +1748,8 @@ writeEditsToFile(FILE* fa, FILE* tsv, const char* hdr, ctx_t* c)
 	while (node_index < nv->size && curr.node_type != -1) {
 		if (curr.node_type == 0) {
 			if (n_ins) {
-				unsigned char draft_char = (unsigned char)seq[curr.s_pos - n_ins];
+				/* (U4) */
+				unsigned char draft_char = curr.s_pos >= n_ins ? (unsigned char)seq[curr.s_pos - n_ins] : (unsigned char)'N';
 				insertion_bases[n_ins] = 0;
 				if (tsv) {
 					fprintf(tsv, "%s\t%u\t%c\t+%s\t%d\n", hdr, pos, draft_char, insertion_bases, num_support);

@@ -32,11 +32,12 @@ class HipParams(ctypes.Structure):
         ("start_grid", ctypes.c_uint32),
         ("node_window", ctypes.c_uint32),
         ("screen_mode", ctypes.c_uint32),
+        ("event_budget", ctypes.c_uint32),
     ]
 
 
 def default_params(**kw):
-    p = HipParams(100, 5, 5, 9.0, 5.0, 0.5, 0.5, 0, 3, 0, 0, 0, 1, 255, 0, 0, 0)
+    p = HipParams(100, 5, 5, 9.0, 5.0, 0.5, 0.5, 0, 3, 0, 0, 0, 1, 255, 0, 0, 0, 0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -401,4 +402,8 @@ PARITY_CONFIGS = [
     (dict(flavor="cbf N iupac"), dict(min_threshold=3, max_threshold=4)),
     (dict(flavor="cbf", hashes=2, bfbytes=50021), dict(min_threshold=2, mode=1)),
     (dict(flavor="cbf sec"), dict(min_threshold=2, max_threshold=5, mode=2, max_insertions=2, max_deletions=2)),
+    # event budget: speculative events parked early, the applied ones re-run to completion
+    (dict(p_sub=2e-2, p_ins=3e-3, p_del=3e-3), dict(start_grid=2, event_budget=4)),
+    (dict(flavor="rep", p_ins=2e-3), dict(start_grid=16, event_budget=40)),
+    (dict(flavor="N lower sec"), dict(mode=1, start_grid=2, event_budget=9)),
 ]

@@ -13,6 +13,7 @@
 namespace nte { WorkCounters g_wc; }
 #include "../../ntedit_amd/host/params.h"
 #include "../../ntedit_amd/host/render.h"
+#include "../../ntedit_amd/host/resolve.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -123,24 +124,43 @@ hostsim_polish(
 			events.push_back(g);
 		}
 	}
-	// arena: generous
+	// arena: generous; like ntedit_hip_polish_batch, a batch that still runs out of it is run again
+	// with four times as much (up to 4 times)
 	u32 arena_chunks = (u32)(events.size() * 4 + n + 1024);
-	std::vector<Item> arena((size_t)arena_chunks * CHUNK_ITEMS);
+	std::vector<Item> arena;
 	u32 arena_next = 0;
+	std::vector<u32> ev_first;
+	bool overflow = false;
+	bool arena_full = false;
+	for (int attempt = 0; attempt < 5; attempt++, arena_chunks *= 4) {
+	arena.assign((size_t)arena_chunks * CHUNK_ITEMS, Item());
+	arena_next = 0;
+	overflow = false;
+	arena_full = false;
+	ev_first.clear();
 	std::vector<Node> nodes(p.node_window);
 	std::vector<u32> ov_pos(p.node_window);
 	std::vector<u8> ov_chr(p.node_window);
 	std::vector<u8> win(2 * p.k + p.max_deletions + 8 + 32);
 	std::vector<u8> prev(p.node_window);
 	std::vector<int16_t> lps(p.node_window);
-	std::vector<u32> ev_first;
-	bool overflow = false;
-
-	u32 ci = 0;
-	for (u64 g : events) {
-		while (ci + 1 < n_contigs && offsets[ci + 1] <= g) {
-			ci++;
+	// contig of every event
+	std::vector<u32> ev_contig(events.size());
+	{
+		u32 ci = 0;
+		for (size_t i = 0; i < events.size(); i++) {
+			while (ci + 1 < n_contigs && offsets[ci + 1] <= events[i]) {
+				ci++;
+			}
+			ev_contig[i] = ci;
 		}
+	}
+	// one event, the way a launch with the given budget runs it (pass 1 + pass 2 of the two-pass scheme)
+	auto run_event = [&](size_t idx, u32 budget) -> u32 {
+		const u64 g = events[idx];
+		const u32 ci = ev_contig[idx];
+		DevParams pe = p;
+		pe.event_budget = budget;
 		EventEnv env;
 		env.seq = (const u8*)bases + offsets[ci];
 		env.batch_end = (const u8*)bases + n;
@@ -149,7 +169,7 @@ hostsim_polish(
 		env.gbase = offsets[ci];
 		env.bitmap = bitmap.data();
 		env.tab = tab;
-		env.p = &p;
+		env.p = &pe;
 		env.bloom = f;
 		env.rep = fr;
 		env.nodes = nodes.data();
@@ -173,6 +193,7 @@ hostsim_polish(
 		if (getenv("HOSTSIM_HIST")) { fprintf(stderr, "EVT %u %u %llu %d\n", start, cover_end, dtc, (int)(m.first_chunk != NONE32)); }
 		if (m.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
 			overflow = true;
+			arena_full = arena_full || (m.flags & EV_ARENA_FULL);
 		}
 		if (m.flags & EV_DEFERRED) {
 			// second pass: the same event again, sweeps allowed
@@ -182,22 +203,52 @@ hostsim_polish(
 			m2.run(start, cover_end);
 			if (m2.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
 				overflow = true;
+				arena_full = arena_full || (m2.flags & EV_ARENA_FULL);
 			}
-			u32 fc2 = m2.finish(start, cover_end);
-			if (fc2 != NONE32) {
-				ev_first.push_back(fc2);
-			}
-			continue;
+			return m2.finish(start, cover_end);
 		}
 		u32 fc = m.finish(start, cover_end);
 		if (getenv("HOSTSIM_DEBUG")) {
 			if (fc != NONE32) { const Item* c = arena.data() + (size_t)fc*CHUNK_ITEMS; for (u32 i=0;i<c[0].w[1];i++) fprintf(stderr,"   item %u: %08x %u %u %u\n", i, c[i].w[0], c[i].w[1], c[i].w[2], c[i].w[3]); }
 			fprintf(stderr, "event contig %u start %u cover_end %u flags %u first_chunk %d nsize %u nbase %u\n", ci, start, cover_end, m.flags, (int)fc, m.nsize, m.nbase);
 		}
+		return fc;
+	};
+	std::vector<u32> first_by_event(events.size(), NONE32);
+	for (size_t i = 0; i < events.size(); i++) {
+		first_by_event[i] = run_event(i, p.event_budget);
+	}
+	// parked events the serial order needs: re-run to completion (what ntedit_hip_polish_batch does)
+	if (!overflow) {
+		nte_host::Resolver rs(arena.data(), arena.size(), first_by_event.data(), events.size());
+		std::vector<u32> rerun;
+		if (!rs.start(rerun)) {
+			return -7;
+		}
+		unsigned rounds = 0;
+		while (!rerun.empty() && !overflow) {
+			for (u32 i : rerun) {
+				first_by_event[i] = run_event(i, 0);
+			}
+			rerun.clear();
+			rounds++;
+			if (!rs.resume(rerun)) {
+				return -7;
+			}
+		}
+		if (getenv("HOSTSIM_DEBUG") || getenv("HOSTSIM_COUNTERS")) {
+			fprintf(stderr, "RESOLVE rounds %u\n", rounds);
+		}
+	}
+	for (u32 fc : first_by_event) {
 		if (fc != NONE32) {
 			ev_first.push_back(fc);
 		}
 	}
+	if (!(overflow && arena_full)) {
+		break;
+	}
+	} // attempt
 	if (getenv("HOSTSIM_COUNTERS")) {
 		fprintf(stderr, "COUNTERS events %zu probes %llu slow_rolls %llu ins_cands %llu del_cands %llu sweeps %llu\n",
 		        events.size(), g_wc.probes, g_wc.slow_rolls, g_wc.ins_cands, g_wc.del_cands, g_wc.sweeps);

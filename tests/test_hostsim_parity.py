@@ -85,3 +85,20 @@ def test_vcf_annotations(tmp_path, oracle_build):
             ob = H.vcf_body(str(tmp_path / "o_variants.vcf"))
             assert ob == H.vcf_body(str(tmp_path / "h_variants.vcf"))
             assert any("CLNSIG=test" in l for l in ob) and any("^NA" in l for l in ob)
+
+
+def test_saturated_filter_chains(tmp_path, oracle_build):
+    """A saturated filter (h=1, ~50 % of the bits set) with a low acceptance bar: the serial run chains edit
+    after edit and hardly ever returns to a clean state, so nearly every speculative event would walk to
+    the end of its contig.  The launch budget parks them; the resolver re-runs the applied ones.  Found by
+    tools/fuzz_parity.py (seed 200059)."""
+    case = H.make_case(str(tmp_path), 200059, n=27022, contigs=2, k=40, hashes=1, p_sub=0.01, p_ins=0.0, p_del=0.002,
+                       flavor="iupac sec", bfbytes=54390)
+    kw = dict(max_insertions=4, max_deletions=0, min_contig_len=41, missing_threshold=9.0, edit_threshold=25.0)
+    H.run_oracle(case["draft"], case["bf"], H.default_params(**kw), str(tmp_path / "o"), case["rep"])
+    rc, nev, nap = H.run_hostsim(H.read_fasta(case["draft"]), H.load_bf(case["bf"]), H.default_params(event_budget=512, **kw),
+                                 str(tmp_path / "h"), H.load_bf(case["rep"]))
+    assert rc == 0
+    assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "h_changes.tsv"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "h_edited.fa"), shallow=False)
+    assert nap < nev / 10  # almost everything was speculation

@@ -1,0 +1,160 @@
+"""Randomised parity hunt: random cases x random parameters, the oracle against
+  * the host build of the event-machine logic (default; runs anywhere), or
+  * the `ntedit` binary on a GPU (--gpu).
+usage: python tools/fuzz_parity.py [--gpu] [--iters N] [--seed S] [--minutes M] [--keep DIR]
+Prints one line per mismatch (and keeps the case directory); exit code 1 if any."""
+import argparse
+import filecmp
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ctypes  # noqa: E402
+import numpy as np  # noqa: E402
+import helpers as H  # noqa: E402
+
+CLAMP = ctypes.CDLL(os.path.join(ROOT, "ntedit_amd", "libntedit_hip.so")).ntedit_hip_params_clamp
+CLAMP.restype = None
+
+
+def random_config(rng):
+    flav = []
+    for f, p in (("N", 0.3), ("lower", 0.2), ("iupac", 0.15), ("exotic", 0.1), ("rep", 0.2), ("sec", 0.2)):
+        if rng.random() < p:
+            flav.append(f)
+    cbf = rng.random() < 0.15
+    if cbf:
+        flav = [f for f in flav if f != "sec"] + ["cbf"]
+    k = int(rng.choice([15, 20, 25, 25, 25, 31, 32, 33, 40, 55, 64]))
+    snv = rng.random() < 0.12
+    n = int(rng.integers(6000, 9000)) if snv else int(rng.integers(8000, 50000))
+    case = dict(n=n, contigs=int(rng.integers(1, 4)), k=k, hashes=int(rng.integers(1, 7)),
+                p_sub=float(rng.choice([5e-4, 2e-3, 1e-2, 3e-2])), p_ins=float(rng.choice([0, 3e-4, 2e-3, 5e-3])),
+                p_del=float(rng.choice([0, 3e-4, 2e-3, 5e-3])), flavor=" ".join(flav))
+    slots_per_kmer = float(rng.choice([4, 8, 16, 40]))
+    nb = max(1024, int(n * case["contigs"] * slots_per_kmer / 8))
+    if rng.random() < 0.5:
+        nb = 1 << int(np.ceil(np.log2(nb)))
+    else:
+        nb += int(rng.integers(0, 64)) * 8 + (0 if cbf else int(rng.integers(0, 8)))
+    case["bfbytes"] = nb // 8 if cbf else nb
+    par = dict(mode=int(rng.choice([0, 0, 1, 2])), mask=int(rng.random() < 0.2),
+               jump=int(rng.choice([1, 2, 3, 3, 3, 5, 7])), max_insertions=int(rng.choice([0, 1, 2, 4, 5, 5])),
+               max_deletions=int(rng.choice([0, 1, 3, 5, 5, 10])), min_contig_len=int(rng.choice([0, 41, 100, 100])))
+    if par["mode"] == 2:
+        par["max_insertions"] = min(par["max_insertions"], 3)
+        par["max_deletions"] = min(par["max_deletions"], 5)
+    if rng.random() < 0.25:
+        par.update(use_ratio=1, missing_ratio=float(rng.choice([0.1, 0.5, 0.9])), edit_ratio=float(rng.choice([0.1, 0.5, 0.9])))
+    else:
+        par.update(missing_threshold=float(rng.choice([1.5, 5.0, 5.0, 9.0, 25.0])),
+                   edit_threshold=float(rng.choice([2.0, 9.0, 9.0, 9.0, 25.0])))
+    if cbf:
+        par.update(min_threshold=int(rng.choice([1, 2, 3])), max_threshold=int(rng.choice([255, 255, 4, 200])))
+    if snv:
+        par["snv"] = 1
+    if rng.random() < 0.3:
+        par["start_grid"] = int(rng.choice([1, 2, 16, 64, 4096]))
+    if rng.random() < 0.3:
+        par["event_budget"] = int(rng.choice([1, 8, 100, 600, 100000]))
+    return case, par
+
+
+def cli_args(hp):
+    return H.oracle_args(hp)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--minutes", type=float, default=0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--keep", default=os.path.join(ROOT, "gpurun_out", "fuzz_failures"))
+    args = ap.parse_args()
+    H.build_oracle()
+    if not args.gpu:
+        H.build_hostsim()
+    t_end = time.time() + args.minutes * 60 if args.minutes else None
+    bad = 0
+    it = 0
+    while it < args.iters or (t_end and time.time() < t_end):
+        if t_end and time.time() >= t_end:
+            break
+        seed = args.seed * 100000 + it
+        it += 1
+        rng = np.random.default_rng(seed)
+        case_kw, par_kw = random_config(rng)
+        tmp = tempfile.mkdtemp(prefix="ntefuzz_")
+        why = None
+        try:
+            case = H.make_case(tmp, seed, **case_kw)
+            hp = H.default_params(**par_kw)
+            # main()'s clamping (ntedit.cpp:2478-2493) is the caller's job: the oracle's and the product's
+            # command lines do it themselves, the host build of the machine gets clamped parameters
+            hp_run = H.default_params(**par_kw)
+            CLAMP(ctypes.byref(hp_run), None, 0)
+            H.run_oracle(case["draft"], case["bf"], hp, os.path.join(tmp, "o"), case["rep"])
+            if args.gpu:
+                cmd = [os.path.join(ROOT, "ntedit_amd", "ntedit"), "-f", case["draft"], "-r", case["bf"], "-b",
+                       os.path.join(tmp, "h")] + (["-e", case["rep"]] if case["rep"] else []) + cli_args(hp)
+                env = dict(os.environ)
+                if "start_grid" in par_kw:
+                    cmd += ["--start-grid", str(par_kw["start_grid"])]
+                if "event_budget" in par_kw:
+                    cmd += ["--event-budget", str(par_kw["event_budget"])]
+                r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+                if r.returncode != 0:
+                    why = "ntedit exit %d: %s" % (r.returncode, r.stderr[-300:])
+            else:
+                rep = H.load_bf(case["rep"]) if case["rep"] else None
+                bf = H.load_bf(case["bf"])
+                recs = H.read_fasta(case["draft"])
+                rc, _, _ = H.run_hostsim(recs, bf, hp_run, os.path.join(tmp, "h"), rep)
+                # the C ABI retries an overflowing batch with a doubled rope window (up to 4 times)
+                win = hp_run.node_window or 6 * bf["k"] + 96
+                for _ in range(4):
+                    if rc != -4:
+                        break
+                    win *= 2
+                    hp_run.node_window = win
+                    rc, _, _ = H.run_hostsim(recs, bf, hp_run, os.path.join(tmp, "h"), rep)
+                if rc != 0:
+                    why = "hostsim rc %d" % rc
+            if why is None:
+                for suf in ("_changes.tsv", "_edited.fa"):
+                    if not filecmp.cmp(os.path.join(tmp, "o" + suf), os.path.join(tmp, "h" + suf), shallow=False):
+                        why = "differs: " + suf
+                        break
+                else:
+                    if H.vcf_body(os.path.join(tmp, "o_variants.vcf")) != H.vcf_body(os.path.join(tmp, "h_variants.vcf")):
+                        why = "differs: _variants.vcf"
+        except subprocess.CalledProcessError as e:
+            why = "oracle/tool failed: %s" % e
+        except subprocess.TimeoutExpired:
+            why = "timeout"
+        if why:
+            bad += 1
+            os.makedirs(args.keep, exist_ok=True)
+            dst = os.path.join(args.keep, "seed%d" % seed)
+            shutil.rmtree(dst, ignore_errors=True)
+            for f in ("truth.fa", "part.fa", "thin.fa", "lo.fa"):
+                try:
+                    os.remove(os.path.join(tmp, f))
+                except OSError:
+                    pass
+            shutil.copytree(tmp, dst)
+            print("MISMATCH seed=%d %s case=%r params=%r" % (seed, why, case_kw, par_kw), flush=True)
+        shutil.rmtree(tmp, ignore_errors=True)
+    print("fuzz: %d iterations, %d mismatches" % (it, bad), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -2074,6 +2074,27 @@ struct Machine
 			cover_end = e.len;
 			return;
 		}
+		if ((u64)start + p.k == e.len) {
+			// findFirstAcceptedKmer stops at i + k < size (ntedit.cpp:527): the reference never
+			// SEEDS its main loop at the last k-mer start of a contig, it only gets there by
+			// rolling on from an earlier accepted k-mer.  Without one this position is never
+			// looked at (visible with -s 1, where every position is assessed).
+			u32 good = p.k - 1; // start .. start+k-2 are accepted bases
+			bool earlier = false;
+			for (u32 i = start; i > 0;) {
+				i--;
+				good = char_code(e.seq[i]) != CODE_BAD ? good + 1 : 0;
+				if (good >= p.k) {
+					earlier = true;
+					break;
+				}
+			}
+			if (!earlier) {
+				flags |= EV_TERMINAL;
+				cover_end = e.len;
+				return;
+			}
+		}
 		bool first = true;
 		u32 steps = 0;
 		NTE_PROF_DECL;

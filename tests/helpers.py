@@ -406,4 +406,29 @@ PARITY_CONFIGS = [
     (dict(p_sub=2e-2, p_ins=3e-3, p_del=3e-3), dict(start_grid=2, event_budget=4)),
     (dict(flavor="rep", p_ins=2e-3), dict(start_grid=16, event_budget=40)),
     (dict(flavor="N lower sec"), dict(mode=1, start_grid=2, event_budget=9)),
+    # a contig of exactly k bases (the 40-base "short" record): never seeded by the reference (ntedit.cpp:527)
+    (dict(n=8000, contigs=2, k=40), dict(snv=1, mask=1, min_contig_len=0)),
+    (dict(n=20000, contigs=2, k=40, flavor="N"), dict(mask=1, min_contig_len=0)),
 ]
+
+
+def make_tail_case(tmp, k=31):
+    """Contigs whose only / first accepted k-mer is the last possible k-mer start: the reference's
+    findFirstAcceptedKmer (ntedit.cpp:527, i + k < size) never seeds there.  Visible with -s 1 -a 1."""
+    os.makedirs(tmp, exist_ok=True)
+    rng = np.random.default_rng(99)
+    truth = random_genome(rng, 3000)
+    write_fasta(os.path.join(tmp, "truth.fa"), [(b"t", truth)])
+    mkbf([os.path.join(tmp, "truth.fa")], os.path.join(tmp, "t.bf"), k=k, hashes=3, nbytes=1 << 14)
+    g = lambda n: random_genome(rng, n)  # noqa: E731
+    draft = [
+        (b"exact", g(k)),                                  # one k-mer, never seeded
+        (b"n_then_k", b"NNNNN" + g(k)),                    # no earlier accepted k-mer
+        (b"short_n_k", g(k - 1) + b"N" + g(k)),            # prefix too short for a k-mer
+        (b"long_n_k", truth[100:400] + b"N" + g(k)),       # earlier k-mers exist: the tail IS reached by rolling
+        (b"k_plus_1", g(k + 1)),                           # two k-mers: the first is seeded, the second rolled into
+        (b"n_k_plus_1", b"N" + g(k + 1)),
+        (b"truth_tail", truth[500:900]),
+    ]
+    write_fasta(os.path.join(tmp, "draft.fa"), draft, width=60)
+    return {"draft": os.path.join(tmp, "draft.fa"), "bf": os.path.join(tmp, "t.bf"), "rep": None}

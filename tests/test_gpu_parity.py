@@ -409,3 +409,20 @@ def test_make_genome_bf_cli(tmp_path, oracle_build):
     # usage errors
     assert subprocess.run([tool, "-k", "25"], capture_output=True).returncode == 1
     assert subprocess.run([tool, "--genome", str(tmp_path / "g1.fa")], capture_output=True).returncode == 1
+
+
+@pytest.mark.parametrize("kw", [dict(snv=1, mask=1), dict(mask=1), dict(snv=1, mode=2)])
+def test_last_kmer_is_never_a_seed_gpu(tmp_path, oracle_build, kw):
+    case = H.make_tail_case(str(tmp_path))
+    hp = H.default_params(min_contig_len=0, **kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"))
+    pol = _fresh()
+    try:
+        pol.set_params(_hip_params(min_contig_len=0, **kw))
+        pol.load_filter_file(case["bf"], 0)
+        pol.polish_records(H.read_fasta(case["draft"]), str(tmp_path / "h"))
+    finally:
+        pol.close()
+    for suf in ("_changes.tsv", "_edited.fa"):
+        assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("h" + suf)), shallow=False), suf
+    assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))

@@ -102,3 +102,15 @@ def test_saturated_filter_chains(tmp_path, oracle_build):
     assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "h_changes.tsv"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "h_edited.fa"), shallow=False)
     assert nap < nev / 10  # almost everything was speculation
+
+
+@pytest.mark.parametrize("kw", [dict(snv=1, mask=1), dict(mask=1), dict(snv=1, mode=2), dict()])
+def test_last_kmer_is_never_a_seed(tmp_path, oracle_build, kw):
+    case = H.make_tail_case(str(tmp_path))
+    hp = H.default_params(min_contig_len=0, **kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"))
+    rc, _, _ = H.run_hostsim(H.read_fasta(case["draft"]), H.load_bf(case["bf"]), hp, str(tmp_path / "h"))
+    assert rc == 0
+    for suf in ("_changes.tsv", "_edited.fa"):
+        assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("h" + suf)), shallow=False), suf
+    assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))

@@ -105,6 +105,15 @@ def main():
                 cmd = [os.path.join(ROOT, "ntedit_amd", "ntedit"), "-f", case["draft"], "-r", case["bf"], "-b",
                        os.path.join(tmp, "h")] + (["-e", case["rep"]] if case["rep"] else []) + cli_args(hp)
                 env = dict(os.environ)
+                # host-side dimensions that must not change a byte: batch size (several pipelined batches),
+                # render threads, gzipped input
+                if rng.random() < 0.5:
+                    cmd += ["--batch-bases", str(int(rng.choice([1, 5000, 30000, 100000])))]
+                if rng.random() < 0.5:
+                    cmd += ["-t", str(int(rng.integers(1, 9)))]
+                if rng.random() < 0.25:
+                    subprocess.run(["gzip", "-k", "-1", case["draft"]], check=True)
+                    cmd[cmd.index("-f") + 1] = case["draft"] + ".gz"
                 if "start_grid" in par_kw:
                     cmd += ["--start-grid", str(par_kw["start_grid"])]
                 if "event_budget" in par_kw:

@@ -62,7 +62,7 @@ def random_config(rng):
     if rng.random() < 0.3:
         par["start_grid"] = int(rng.choice([1, 2, 16, 64, 4096]))
     if rng.random() < 0.3:
-        par["event_budget"] = int(rng.choice([1, 8, 100, 600, 100000]))
+        par["event_budget"] = int(rng.choice([1, 8, 100, 600, 5000]))
     return case, par
 
 

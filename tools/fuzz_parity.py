@@ -31,7 +31,7 @@ def random_config(rng):
     cbf = rng.random() < 0.15
     if cbf:
         flav = [f for f in flav if f != "sec"] + ["cbf"]
-    k = int(rng.choice([15, 20, 25, 25, 25, 31, 32, 33, 40, 55, 64]))
+    k = int(rng.choice([12, 15, 20, 25, 25, 25, 31, 32, 33, 40, 55, 64, 96, 128, 200]))
     snv = rng.random() < 0.12
     n = int(rng.integers(6000, 9000)) if snv else int(rng.integers(8000, 50000))
     case = dict(n=n, contigs=int(rng.integers(1, 4)), k=k, hashes=int(rng.integers(1, 7)),

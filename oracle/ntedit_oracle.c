@@ -28,7 +28,7 @@
 #include <time.h>
 #include <zlib.h>
 
-ora_counters ora_ctr = { 0, 0, 0 };
+__thread ora_counters ora_ctr = { 0, 0, 0 }; /* per thread (ora_polish_batch_flat_mt) */
 
 /* ------------------------------------------------------------------ ntHash2 */
 /* btllib nthash_consts: SEED_A/C/G/T, SEED_N = 0, CP_OFF = 7, MULTISHIFT = 27,
@@ -2473,4 +2473,94 @@ ora_polish_batch_flat(
 		fclose(tsv);
 	}
 	return total;
+}
+
+
+/* ------------------------------------------------------------------ timing driver
+ * The reference parallelises across contigs only (OpenMP loop, ntedit.cpp:2213-2253: every thread
+ * takes the next record under a critical section and polishes it).  Same scheme with pthreads, for
+ * the cpu_baseline leg of bench.py: nothing is written, the return value is the bases polished. */
+#include <pthread.h>
+
+typedef struct
+{
+	const char* bases;
+	const uint64_t* offsets;
+	const uint32_t* lens;
+	uint32_t n_contigs;
+	const ora_params* p;
+	const ora_bf* bf;
+	const ora_bf* rep;
+	uint32_t next; /* next contig to hand out */
+	uint64_t total;
+	pthread_mutex_t mu;
+} mt_job;
+
+static void*
+mt_worker(void* arg)
+{
+	mt_job* j = (mt_job*)arg;
+	for (;;) {
+		pthread_mutex_lock(&j->mu);
+		const uint32_t i = j->next < j->n_contigs ? j->next++ : UINT32_MAX;
+		pthread_mutex_unlock(&j->mu);
+		if (i == UINT32_MAX) {
+			return NULL;
+		}
+		char* seq = (char*)malloc((size_t)j->lens[i] + 1);
+		memcpy(seq, j->bases + j->offsets[i], j->lens[i]);
+		seq[j->lens[i]] = 0;
+		ora_polish_contig("c", seq, j->lens[i], j->p, j->bf, j->rep, NULL, NULL);
+		free(seq);
+		pthread_mutex_lock(&j->mu);
+		j->total += j->lens[i];
+		pthread_mutex_unlock(&j->mu);
+	}
+}
+
+uint64_t
+ora_polish_batch_flat_mt(
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    uint32_t n_contigs,
+    const uint8_t* bf_data,
+    uint64_t bf_bytes,
+    unsigned hash_num,
+    unsigned k,
+    const ora_params* params,
+    unsigned n_threads)
+{
+	ora_bf bf;
+	memset(&bf, 0, sizeof bf);
+	bf.data = (uint8_t*)bf_data;
+	bf.bytes = bf_bytes;
+	bf.bits = bf_bytes * 8;
+	bf.hash_num = hash_num;
+	bf.k = k;
+	ora_params p = *params;
+	p.secbf = 0;
+	ora_params_finalize(&p, &bf);
+	mt_job j;
+	memset(&j, 0, sizeof j);
+	j.bases = bases;
+	j.offsets = offsets;
+	j.lens = lens;
+	j.n_contigs = n_contigs;
+	j.p = &p;
+	j.bf = &bf;
+	pthread_mutex_init(&j.mu, NULL);
+	if (n_threads < 1) {
+		n_threads = 1;
+	}
+	pthread_t* th = (pthread_t*)calloc(n_threads, sizeof(pthread_t));
+	for (unsigned t = 0; t < n_threads; t++) {
+		pthread_create(&th[t], NULL, mt_worker, &j);
+	}
+	for (unsigned t = 0; t < n_threads; t++) {
+		pthread_join(th[t], NULL);
+	}
+	free(th);
+	pthread_mutex_destroy(&j.mu);
+	return j.total;
 }

@@ -175,12 +175,26 @@ uint64_t ora_polish_batch_flat(
     const char* fa_path,
     const char* tsv_path);
 
+/* the same, contigs handed out to n_threads worker threads the way the reference's OpenMP loop does
+ * (ntedit.cpp:2213-2253); timing only: nothing is written */
+uint64_t ora_polish_batch_flat_mt(
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    uint32_t n_contigs,
+    const uint8_t* bf_data,
+    uint64_t bf_bytes,
+    unsigned hash_num,
+    unsigned k,
+    const ora_params* params,
+    unsigned n_threads);
+
 /* counters for work-profile checks */
 typedef struct
 {
 	uint64_t rolls, contains, bitreads;
 } ora_counters;
-extern ora_counters ora_ctr;
+extern __thread ora_counters ora_ctr;
 
 #ifdef __cplusplus
 }

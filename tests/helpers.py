@@ -112,6 +112,27 @@ def oracle_polish_flat(blob, offsets, lens, bits, hash_num, k, names=None, fa_pa
         fa_path.encode() if fa_path else None, tsv_path.encode() if tsv_path else None)
 
 
+def oracle_polish_flat_mt(blob, offsets, lens, bits, hash_num, k, threads):
+    """Timing only: the oracle with contigs handed out to `threads` worker threads like the reference's
+    OpenMP loop (default parameters); returns the number of bases polished."""
+    import numpy as np
+    lib = oracle_lib()
+    lib.ora_polish_batch_flat_mt.restype = ctypes.c_uint64
+    p = OraParams()
+    lib.ora_params_default(ctypes.byref(p))
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    if isinstance(blob, np.ndarray):
+        bptr = ctypes.c_void_p(np.ascontiguousarray(blob, dtype=np.uint8).ctypes.data)
+    else:
+        bptr = ctypes.cast(ctypes.c_char_p(blob), ctypes.c_void_p)
+    return lib.ora_polish_batch_flat_mt(
+        bptr, offsets.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p),
+        ctypes.c_uint32(len(lens)), bits.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bits.size),
+        ctypes.c_uint(hash_num), ctypes.c_uint(k), ctypes.byref(p), ctypes.c_uint(threads))
+
+
 _hostsim = None
 
 

@@ -1470,15 +1470,9 @@ ntedit_hip_polish_batch(
 			} else {
 			HIP_TRY(c, hipEventRecord(c->ev[4], sB));
 			HIP_TRY(c, hipStreamSynchronize(sB));
-			// keep the events that produced output, in position order (compacted in place)
-			u32* first = (u32*)r->first_buf.p;
-			size_t w = 0;
-			for (u64 i = 0; i < ev_total; i++) {
-				if (first[i] != NONE32) {
-					first[w++] = first[i];
-				}
-			}
-			r->n_ev_first = w;
+			// one entry per event, in position order; NONE32 = the event produced nothing (the
+			// renderer skips those)
+			r->n_ev_first = ev_total;
 			// timings: screening = sum of its launches (they may overlap machine kernels)
 			float ms_screen = 0.f;
 			const size_t n_scr = pipelined ? n_ch : 1;

@@ -491,6 +491,9 @@ render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigO
 	bool any = false;
 	for (; ev < ev_end; ev++) {
 		const uint32_t fc = v.ev_first[ev];
+		if (fc == nte::NONE32) {
+			continue;
+		}
 		const Item& hdr = arena[(size_t)fc * nte::CHUNK_ITEMS + 1]; // (bounds checked by the caller)
 		const uint32_t start = hdr.w[1], cover_end = hdr.w[2];
 		if (start < cover) {
@@ -729,6 +732,10 @@ render_batch(
 			ev_begin[ci] = ev;
 			while (ev < n_events) {
 				const uint32_t fc = ev_first[ev];
+				if (fc == nte::NONE32) {
+					ev++; // an event without output
+					continue;
+				}
 				if ((size_t)fc * nte::CHUNK_ITEMS + 1 >= arena_items) {
 					return -1;
 				}

@@ -32,8 +32,8 @@ struct RenderOptions
 };
 
 // arena:    host copy of the chunk arena
-// ev_first: first chunk of every event that produced output, ordered by
-//           global start position (contig order, then position)
+// ev_first: first chunk of every event, ordered by global start position (contig order, then
+//           position); nte::NONE32 entries (events without output) are skipped
 // fa / tsv: may be nullptr (that stream is skipped)
 int render_batch(
     const nte::Item* arena,

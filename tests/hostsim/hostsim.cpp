@@ -240,11 +240,7 @@ hostsim_polish(
 			fprintf(stderr, "RESOLVE rounds %u\n", rounds);
 		}
 	}
-	for (u32 fc : first_by_event) {
-		if (fc != NONE32) {
-			ev_first.push_back(fc);
-		}
-	}
+	ev_first = first_by_event; // (one entry per event, NONE32 where there is no output, as the C ABI hands them on)
 	if (!(overflow && arena_full)) {
 		break;
 	}

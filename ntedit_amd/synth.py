@@ -85,10 +85,13 @@ class SyntheticJob:
     mutated draft, laid out as one batch (contigs separated by '\\n') in HBM."""
 
     def __init__(self, polisher, total_bases, k=25, hash_num=3, filter_bytes=1 << 32, seed=20251031,
-                 draft_seed=None, device="cuda", build_filter="alloc", n_runs=True, mutate=True):
+                 draft_seed=None, device="cuda", build_filter="alloc", n_runs=True, mutate=True,
+                 rep_filter_bytes=0, rep_fraction=0.01):
         """build_filter: "alloc" = allocate a filter in the library and fill it; "insert" = fill the
         filter the polisher already has (e.g. a shared tensor); False = leave the filter alone.
-        mutate=False keeps the draft identical to the truth genome (every k-mer is in the filter)."""
+        mutate=False keeps the draft identical to the truth genome (every k-mer is in the filter).
+        rep_filter_bytes > 0 also builds a SECONDARY ("repeat", -e) filter holding the k-mers of the first
+        rep_fraction of every truth contig."""
         self.total_bases = int(total_bases)
         dev = torch.device(device)
         lens = contig_lengths(total_bases, seed)
@@ -98,6 +101,8 @@ class SyntheticJob:
         gen_d.manual_seed((seed + 1) if draft_seed is None else draft_seed)
         if build_filter == "alloc":
             polisher.filter_alloc(filter_bytes, hash_num, k)
+        if rep_filter_bytes:
+            polisher.filter_alloc(rep_filter_bytes, hash_num, k, slot=1)
         parts, offs, dlens = [], [], []
         pos = 0
         nl = torch.tensor([10], dtype=torch.uint8, device=dev)
@@ -107,6 +112,8 @@ class SyntheticJob:
                 tb = codes_to_bytes(t)
                 torch.cuda.synchronize(dev)
                 polisher.filter_insert(None, device_ptr=tb.data_ptr(), n=tb.numel())
+                if rep_filter_bytes:
+                    polisher.filter_insert(None, slot=1, device_ptr=tb.data_ptr(), n=max(k, int(tb.numel() * rep_fraction)))
                 del tb
             d = codes_to_bytes(mutate_codes(t, gen_d) if mutate else t)
             if n_runs:

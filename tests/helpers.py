@@ -91,25 +91,32 @@ class OraParams(ctypes.Structure):
                 ("max_threshold", ctypes.c_uint)]
 
 
-def oracle_polish_flat(blob, offsets, lens, bits, hash_num, k, names=None, fa_path=None, tsv_path=None):
-    """The oracle over an in-memory batch and an in-memory filter (default parameters, 1 thread);
-    returns the number of bases it processed."""
+def oracle_polish_flat(blob, offsets, lens, bits, hash_num, k, names=None, fa_path=None, tsv_path=None,
+                       rep_bits=None, rep_hash_num=0, **params):
+    """The oracle over an in-memory batch and in-memory filter(s) (default parameters unless overridden
+    by name, 1 thread); returns the number of bases it processed."""
     import numpy as np
     lib = oracle_lib()
     lib.ora_polish_batch_flat.restype = ctypes.c_uint64
     p = OraParams()
     lib.ora_params_default(ctypes.byref(p))
+    for name, v in params.items():
+        setattr(p, name, v)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     lens = np.ascontiguousarray(lens, dtype=np.uint32)
     bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    rep_ptr, rep_n = None, 0
+    if rep_bits is not None:
+        rep_bits = np.ascontiguousarray(rep_bits, dtype=np.uint8)
+        rep_ptr, rep_n = rep_bits.ctypes.data_as(ctypes.c_void_p), rep_bits.size
     arr = None
     if names is not None:
         arr = (ctypes.c_char_p * max(len(names), 1))(*names)
     return lib.ora_polish_batch_flat(
         ctypes.c_char_p(blob), offsets.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), arr,
         ctypes.c_uint32(len(lens)), bits.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bits.size),
-        ctypes.c_uint(hash_num), ctypes.c_uint(k), None, ctypes.c_uint64(0), ctypes.c_uint(0), ctypes.byref(p),
-        fa_path.encode() if fa_path else None, tsv_path.encode() if tsv_path else None)
+        ctypes.c_uint(hash_num), ctypes.c_uint(k), rep_ptr, ctypes.c_uint64(rep_n), ctypes.c_uint(rep_hash_num),
+        ctypes.byref(p), fa_path.encode() if fa_path else None, tsv_path.encode() if tsv_path else None)
 
 
 def oracle_polish_flat_mt(blob, offsets, lens, bits, hash_num, k, threads):

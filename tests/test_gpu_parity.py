@@ -321,7 +321,7 @@ def test_full_size_properties(tmp_path, oracle_build):
         res.write(host, job.offsets, job.lens, names, fa, tsv, append=True)
         st = res.stats()
         res.free()
-        whole = (st.absent_kmers, st.substitutions, st.insertions, st.deletions, st.events_applied)
+        whole = (st.absent_kmers, st.substitutions, st.insertions, st.deletions)  # (event counts depend on the grid)
         assert st.insertions > 0 and st.deletions > 0
         # the synthetic error rates: 0.1% substitutions, 0.01% indels -- nearly all are repaired
         assert 0.8e-3 * job.n_bases < st.substitutions < 1.2e-3 * job.n_bases
@@ -338,7 +338,7 @@ def test_full_size_properties(tmp_path, oracle_build):
             del half
             r.write(host[o0:o1], offs_h, job.lens[lo:hi], names[lo:hi], None, None)
             s = r.stats()
-            parts.append((s.absent_kmers, s.substitutions, s.insertions, s.deletions, s.events_applied))
+            parts.append((s.absent_kmers, s.substitutions, s.insertions, s.deletions))
             r.free()
         assert tuple(a + b for a, b in zip(*parts)) == whole
 
@@ -426,3 +426,76 @@ def test_last_kmer_is_never_a_seed_gpu(tmp_path, oracle_build, kw):
     for suf in ("_changes.tsv", "_edited.fa"):
         assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("h" + suf)), shallow=False), suf
     assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))
+
+
+def test_full_size_deep_search_secondary(tmp_path, oracle_build, capsys):
+    """BASELINE.json configs[4] at full size: 3 Gbp draft, k=35, primary + secondary ("repeat", -e) 4 GiB
+    filters, -i 5 -d 9 (after the reference's clamp of -i 9).  Partition independence of the edit counts and
+    an oracle spot check of contigs rendered from the full batch."""
+    import torch
+    import ntedit_amd
+    from ntedit_amd.synth import SyntheticJob
+
+    total = float(os.environ.get("NTEDIT_FULL_BASES", "3e9"))
+    fbytes = int(os.environ.get("NTEDIT_FULL_FILTER", str(1 << 32)))
+    kw = dict(max_insertions=5, max_deletions=9)
+    pol = ntedit_amd.Polisher(0)
+    try:
+        job = SyntheticJob(pol, total, k=35, hash_num=3, filter_bytes=fbytes, rep_filter_bytes=fbytes)
+        pol.set_params(ntedit_amd.default_params(**kw))
+        res = pol.polish_batch(None, job.offsets, job.lens, device_ptr=job.device_ptr, n=job.n_bytes)
+        res.free()  # (warm-up: buffers)
+        res = pol.polish_batch(None, job.offsets, job.lens, device_ptr=job.device_ptr, n=job.n_bytes)
+        nc = len(job.lens)
+        names = [b"contig%d" % i for i in range(nc)]
+        host = job.batch.cpu().numpy()
+        fa, tsv = str(tmp_path / "full_edited.fa"), str(tmp_path / "full_changes.tsv")
+        pol.write_tsv_header(tsv)
+        res.write(host, job.offsets, job.lens, names, fa, tsv, append=True)
+        st = res.stats()
+        res.free()
+        with capsys.disabled():
+            print("\n[configs[4]] %.0f Mbases in %.1f ms (screen %.1f ms): %.0f Mbases/s; %d subs %d ins %d del" %
+                  (job.n_bases / 1e6, st.ms_total, st.ms_screen, job.n_bases / st.ms_total / 1e3,
+                   st.substitutions, st.insertions, st.deletions))
+        whole = (st.absent_kmers, st.substitutions, st.insertions, st.deletions)  # (event counts depend on the grid)
+        assert st.substitutions > 0 and st.insertions > 0 and st.deletions > 0
+        parts = []
+        for lo, hi in ((0, nc // 2), (nc // 2, nc)):
+            o0 = int(job.offsets[lo])
+            o1 = int(job.offsets[hi - 1]) + int(job.lens[hi - 1]) + 1
+            offs_h = job.offsets[lo:hi] - np.uint64(o0)
+            half = job.batch[o0:o1].clone()
+            torch.cuda.synchronize()
+            r = pol.polish_batch(None, offs_h, job.lens[lo:hi], device_ptr=half.data_ptr(), n=o1 - o0)
+            del half
+            r.write(host[o0:o1], offs_h, job.lens[lo:hi], names[lo:hi], None, None)
+            s = r.stats()
+            parts.append((s.absent_kmers, s.substitutions, s.insertions, s.deletions))
+            r.free()
+        assert tuple(a + b for a, b in zip(*parts)) == whole
+        order = np.argsort(job.lens, kind="stable")
+        pick = sorted({int(order[0]), int(order[len(order) // 8]), int(order[len(order) // 3])})
+        blob, offs, lens, pos = [], [], [], 0
+        for i in pick:
+            o, l = int(job.offsets[i]), int(job.lens[i])
+            blob.append(host[o:o + l + 1].tobytes())
+            offs.append(pos)
+            lens.append(l)
+            pos += l + 1
+        bits, rep = pol.filter_download(0), pol.filter_download(1)
+        k, h, nbytes, _ = pol.filter_info(0)
+        ofa, otsv = str(tmp_path / "ora_edited.fa"), str(tmp_path / "ora_changes.tsv")
+        done = H.oracle_polish_flat(b"".join(blob), offs, lens, bits, h, k, names=[names[i] for i in pick],
+                                    fa_path=ofa, tsv_path=otsv, rep_bits=rep, rep_hash_num=h, **kw)
+        assert done == sum(lens)
+        want = [names[i] for i in pick]
+        got_fa, got_tsv = _sample_records(fa, tsv, want)
+        exp_fa, exp_tsv = _sample_records(ofa, otsv, want)
+        assert set(got_fa) == set(want) == set(exp_fa)
+        for w in want:
+            assert got_fa[w] == exp_fa[w], w
+            assert got_tsv[w] == exp_tsv[w], w
+        assert sum(len(v) for v in exp_tsv.values()) > 100
+    finally:
+        pol.close()

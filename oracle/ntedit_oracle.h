@@ -17,6 +17,11 @@
  *     ntedit.cpp:24-26) and is absent from /root/reference.  The restatement
  *     below follows the published ntHash2 / btllib algorithm from memory.
  *     ==> hashing parity with real btllib-built filters is "PARITY UNPINNED".
+ *     (Supporting evidence, not a pin by the rule above: the restatement reproduces the nine
+ *     64-bit words of btllib's own unit test vector -- "ACATGCATGCA", k=5, 3 hashes, btllib
+ *     tests/nthash.cpp, quoted from the published test suite -- tests/test_oracle_kats.py.
+ *     What no vector covers: the bit order / modulo of the filter array, the .bf header, and
+ *     the treatment of non-ACGT characters.)
  *   - the reference cannot be compiled here (needs btllib + Boost headers the
  *     image lacks), so there is no oracle/_ref build.
  */

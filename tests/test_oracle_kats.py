@@ -125,3 +125,30 @@ def test_host_device_header_matches_oracle_screen(tmp_path, oracle_build):
                                 ctypes.c_uint32(h), ctypes.c_uint32(k), got.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(0), ctypes.c_uint32(1))
         assert rc == 0
         assert np.array_equal(got, want)
+
+
+def test_btllib_unit_test_vector(oracle_build):
+    """btllib's own ntHash unit test (btllib tests/nthash.cpp): the three 5-mers of "ACATGCATGCA" with 3
+    hashes each.  btllib is not part of /root/reference, so these nine words are quoted from its published
+    test suite, not taken from a file here -- the hashing therefore stays formally "parity unpinned" --
+    but nine matching 64-bit words cannot be a coincidence: seeds, split rotation, canonical = fh + rh and
+    the multi-hash extension (i ^ k * MULTISEED, >> 27) are the ones btllib computes."""
+    lib = H.oracle_lib()
+    lib.ora_extend_hashes.argtypes = [ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint64)]
+    seq, k = b"ACATGCATGCA", 5
+    want = [
+        (0xF59ECB45F0E22B9C, 0x4969C33AC240C129, 0x688D616F0D7E08C3),
+        (0x38CC00F940AEBDAE, 0xAB7E1B110E086FC6, 0x011A1818BCFDD553),
+        (0x603A48C5A11C794A, 0xE66016E61816B9C4, 0xC5B13CB146996FFE),
+    ]
+    fh = lib.ora_base_forward_hash(seq[:k], k)
+    rh = lib.ora_base_reverse_hash(seq[:k], k)
+    for i, w in enumerate(want):
+        if i:
+            # by rolling, the way the hot path gets there
+            fh = lib.ora_next_forward_hash(fh, k, seq[i - 1], seq[i + k - 1])
+            rh = lib.ora_next_reverse_hash(rh, k, seq[i - 1], seq[i + k - 1])
+            assert fh == lib.ora_base_forward_hash(seq[i:i + k], k)
+        hv = (ctypes.c_uint64 * 3)()
+        lib.ora_extend_hashes((fh + rh) & (2**64 - 1), k, 3, hv)
+        assert tuple(hv) == w

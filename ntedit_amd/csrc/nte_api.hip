@@ -1197,6 +1197,8 @@ ntedit_hip_polish_batch(
 				a.lds_slab = (u32)slab;
 				dyn2 = (size_t)(win_area + slab * per_block);
 			}
+			(void)hipMemsetAsync(a.work_counter, 0, 4, sB);
+			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] wave launch: blocks %llu events %llu dyn %zu lds_slab %u counter %p\n", (unsigned long long)b2, (unsigned long long)a.n_events, dyn2, a.lds_slab, (void*)a.work_counter); }
 			launch_k_machine_wave((unsigned)b2, dyn2, sB, a);
 		};
 		for (size_t j = 0; j < n_ch && status == 0; j++) {
@@ -1309,18 +1311,22 @@ ntedit_hip_polish_batch(
 			a.deferred = (u32*)c->deferred.p;
 			a.n_deferred = d_ndef;
 			a.n_unfinished = (u32*)((char*)c->counters.p + 52);
+			a.work_counter = (u32*)((char*)c->counters.p + 60);
 			if (n_ch != 1) {
 				a.p.event_budget = 0; // (parked events are re-run per batch: single-chunk batches only)
 			}
 			HIP_TRY(c, hipMemsetAsync(d_ndef, 0, 4, sB));
 			HIP_TRY(c, hipEventRecord(c->ev[3], sB));
 			// pass 1: every event, indel sweeps postponed
+			HIP_TRY(c, hipMemsetAsync(a.work_counter, 0, 4, sB));
+			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] pass1 launch: blocks %llu events %llu\n", (unsigned long long)blocks, (unsigned long long)a.n_events); }
 			launch_k_machine_thread((unsigned)blocks, dyn_lds, sB, a);
 			HIP_TRY(c, hipGetLastError());
 			u32 h_tail[4] = { 0, 0, 0, 0 };
 			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
 			HIP_TRY(c, hipEventRecord(c->ev[5], sB));
 			HIP_TRY(c, hipStreamSynchronize(sB));
+			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] pass1 done: deferred %u status %u\n", h_tail[3], h_tail[2]); }
 			const u32 n_def = h_tail[3];
 			deferred_total += n_def;
 			status = h_tail[2];
@@ -1349,6 +1355,7 @@ ntedit_hip_polish_batch(
 			HIP_TRY(c, hipEventRecord(c->ev[4], sB));
 			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
 			HIP_TRY(c, hipStreamSynchronize(sB));
+			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] pass2 done: status %u\n", h_tail[2]); }
 			status = h_tail[2];
 			float p1 = 0.f, p2 = 0.f;
 			(void)hipEventElapsedTime(&p1, c->ev[3], c->ev[5]);

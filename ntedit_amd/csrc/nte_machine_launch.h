@@ -46,6 +46,10 @@ struct MachineArgs
 	u32* deferred;
 	u32* n_deferred;
 	u32* n_unfinished; // events parked by the budget (p.event_budget) in this launch
+	// dynamic work distribution: every worker (thread / wavefront) takes the next event from this
+	// counter (zeroed before the launch) -- event costs are heavy-tailed, a static split leaves most of
+	// the chip waiting for the unluckiest worker
+	u32* work_counter;
 };
 
 constexpr int MACHINE_TPB = 256;

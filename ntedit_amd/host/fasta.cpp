@@ -6,31 +6,83 @@
 
 namespace nte_host {
 
-// large reads go straight from the file into buf_ when the input is not compressed
+// large reads go straight from the file into the block when the input is not compressed
 // (zlib copies directly once a request is at least twice its own buffer)
 static const int BUFSZ = 4 << 20;
 
 FastaReader::FastaReader(const char* path)
   : f_(gzopen(path, "r"))
-  , buf_((unsigned char*)malloc(BUFSZ))
+  , buf_(nullptr)
   , begin_(0)
   , end_(0)
   , eof_(false)
   , last_char_(0)
   , hit_nl_(false)
   , failed_(false)
+  , head_(0)
+  , tail_(0)
+  , cur_(-1)
+  , stop_(false)
 {
+	for (int i = 0; i < NSLOTS; i++) {
+		slot_[i] = nullptr;
+		slot_len_[i] = 0;
+	}
 	if (f_) {
 		gzbuffer(f_, 1 << 17);
+		for (int i = 0; i < NSLOTS; i++) {
+			slot_[i] = (unsigned char*)malloc(BUFSZ);
+		}
+		io_ = std::thread([this]() { io_loop_(); });
 	}
 }
 
 FastaReader::~FastaReader()
 {
+	if (io_.joinable()) {
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			stop_ = true;
+		}
+		cv_.notify_all();
+		io_.join();
+	}
 	if (f_) {
 		gzclose(f_);
 	}
-	free(buf_);
+	for (int i = 0; i < NSLOTS; i++) {
+		free(slot_[i]);
+	}
+}
+
+// I/O thread: reads (and, for .gz, inflates) the file block by block ahead of the parser
+void
+FastaReader::io_loop_()
+{
+	for (;;) {
+		int s;
+		{
+			std::unique_lock<std::mutex> lk(mu_);
+			cv_.wait(lk, [&]() { return stop_ || head_ - tail_ < NSLOTS; });
+			if (stop_) {
+				return;
+			}
+			s = (int)(head_ % NSLOTS);
+		}
+		int n = gzread(f_, slot_[s], BUFSZ);
+		if (n < 0) {
+			n = 0;
+		}
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			slot_len_[s] = n;
+			head_++;
+		}
+		cv_.notify_all();
+		if (n == 0) {
+			return; // end of file (an empty block marks it)
+		}
+	}
 }
 
 bool
@@ -39,13 +91,23 @@ FastaReader::fill_()
 	if (eof_) {
 		return false;
 	}
-	begin_ = 0;
-	end_ = gzread(f_, buf_, BUFSZ);
-	if (end_ <= 0) {
-		end_ = 0;
+	std::unique_lock<std::mutex> lk(mu_);
+	if (cur_ >= 0) {
+		tail_++; // the block the parser has finished with goes back to the I/O thread
+		cur_ = -1;
+		cv_.notify_all();
+	}
+	cv_.wait(lk, [&]() { return head_ > tail_; });
+	const int s = (int)(tail_ % NSLOTS);
+	if (slot_len_[s] <= 0) {
 		eof_ = true;
+		begin_ = end_ = 0;
 		return false;
 	}
+	cur_ = s;
+	buf_ = slot_[s];
+	begin_ = 0;
+	end_ = slot_len_[s];
 	return true;
 }
 
@@ -92,7 +154,7 @@ bool
 FastaReader::next(std::string& header, std::string& seq)
 {
 	int c;
-	if (failed_) {
+	if (failed_ || !f_) {
 		return false;
 	}
 	if (last_char_ == 0) {

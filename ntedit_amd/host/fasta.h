@@ -2,9 +2,13 @@
 // driver.  Record semantics follow what the reference gets from kseq
 // (lib/kseq.h:176-215 as used at ntedit.cpp:2223-2230): name = header text up
 // to the first whitespace, comment = the rest of the header line, sequence =
-// all following lines concatenated.  Own implementation on top of zlib.
+// all following lines concatenated.  Own implementation on top of zlib; the file is read
+// (and inflated) block by block by a second thread, ahead of the parser.
 #pragma once
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <zlib.h>
 
 namespace nte_host {
@@ -24,12 +28,24 @@ class FastaReader
 	int getc_();
 	bool getline_(std::string& out, size_t base, bool strip_cr);
 	std::string line_;
+	void io_loop_();
 	gzFile f_;
-	unsigned char* buf_;
+	unsigned char* buf_; // the block being parsed
+
 	int begin_, end_;
 	bool eof_;
 	int last_char_;
 	bool hit_nl_, failed_;
+	// blocks are read (and inflated) ahead of the parser by a second thread
+	static const int NSLOTS = 4;
+	unsigned char* slot_[NSLOTS];
+	int slot_len_[NSLOTS];
+	unsigned long long head_, tail_; // blocks produced / consumed
+	int cur_;
+	bool stop_;
+	std::mutex mu_;
+	std::condition_variable cv_;
+	std::thread io_;
 };
 
 } // namespace nte_host

@@ -25,6 +25,7 @@
 #include <getopt.h>
 #include <sstream>
 #include <string>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <vector>
 
@@ -450,6 +451,12 @@ main(int argc, char** argv)
 	for (Work& w : pool) {
 		// (address space only: pages are touched as the batch fills)
 		w.b.blob.reserve((size_t)(batch_bases < (1ull << 32) ? batch_bases : (1ull << 32)) + (1 << 20));
+		// first touch of a fresh batch buffer is a page fault per 4 KiB: ask for huge pages
+		const uintptr_t lo = ((uintptr_t)w.b.blob.data() + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+		const uintptr_t hi = ((uintptr_t)w.b.blob.data() + w.b.blob.capacity()) & ~(uintptr_t)((2u << 20) - 1);
+		if (hi > lo) {
+			(void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
+		}
 	}
 	std::thread reader_thread([&]() {
 		std::string hdr;

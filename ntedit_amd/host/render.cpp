@@ -9,6 +9,7 @@
 #include <ctime>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -159,31 +160,38 @@ struct Piece
 	size_t n;
 };
 
-// everything one contig contributes to the three output streams
+// everything one work unit (a run of consecutive contigs) contributes to the three output streams
 struct ContigOut
 {
+	// scratch of the contig being rendered
 	std::vector<RNode> nodes;
 	std::vector<RSub> subs;
 	std::vector<char> seq; // private copy once a character changes
 	bool terminated = false;
+	// output of the unit
 	std::vector<Piece> fa;
 	std::string text, tsv, vcf;
+	std::deque<std::vector<char>> seq_keep; // modified contigs the pieces point into
 	RenderStats st;
 	int rc = 0;
 	bool ready = false;
 
 	void reset()
 	{
-		nodes.clear();
-		subs.clear();
-		seq.clear();
-		terminated = false;
 		fa.clear();
 		text.clear();
 		tsv.clear();
 		vcf.clear();
+		seq_keep.clear();
 		st = RenderStats();
 		rc = 0;
+	}
+	void begin_contig()
+	{
+		nodes.clear();
+		subs.clear();
+		seq.clear();
+		terminated = false;
 	}
 	void fa_text(const char* s, size_t n)
 	{
@@ -480,7 +488,7 @@ struct BatchView
 void
 render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigOut& cs)
 {
-	cs.reset();
+	cs.begin_contig();
 	const char* seq = v.bases + v.offsets[ci];
 	const uint32_t len = v.lens[ci];
 	const Item* arena = v.arena;
@@ -588,7 +596,13 @@ render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigO
 			chunk = next;
 		}
 	}
-	const char* out_seq = cs.seq.empty() ? seq : cs.seq.data();
+	const char* out_seq = seq;
+	if (!cs.seq.empty()) {
+		// the record's pieces will point into the modified copy: park it with the unit
+		cs.seq_keep.emplace_back(std::move(cs.seq));
+		cs.seq.clear();
+		out_seq = cs.seq_keep.back().data();
+	}
 	if (!any) {
 		// untouched contig: header + sequence + newline
 		if (v.want_fa) {
@@ -752,6 +766,31 @@ render_batch(
 		ev_begin[n_contigs] = ev;
 	}
 
+	// work units: runs of consecutive contigs of about a megabase (one hand-over, one gather write and one
+	// set of buffers per unit, not per contig: fragmented assemblies have millions of contigs)
+	std::vector<uint32_t> unit_begin;
+	{
+		uint64_t acc = 0;
+		uint32_t cnt = 0;
+		for (uint32_t ci = 0; ci < n_contigs; ci++) {
+			if (ci == 0 || acc >= v.opt.unit_bases || cnt >= 8192) {
+				unit_begin.push_back(ci);
+				acc = 0;
+				cnt = 0;
+			}
+			acc += lens[ci];
+			cnt++;
+		}
+		unit_begin.push_back(n_contigs);
+	}
+	const uint32_t n_units = (uint32_t)unit_begin.size() - 1;
+	auto render_unit = [&](uint32_t u, ContigOut& o) {
+		o.reset();
+		for (uint32_t ci = unit_begin[u]; ci < unit_begin[u + 1] && !o.rc; ci++) {
+			render_contig(v, ci, ev_begin[ci], ev_begin[ci + 1], o);
+		}
+	};
+
 	unsigned T = v.opt.threads;
 	if (T == 0) {
 		T = std::thread::hardware_concurrency();
@@ -759,13 +798,13 @@ render_batch(
 			T = 8;
 		}
 	}
-	if (T > n_contigs) {
-		T = n_contigs;
+	if (T > n_units) {
+		T = n_units;
 	}
 	if (T <= 1) {
 		ContigOut o;
-		for (uint32_t ci = 0; ci < n_contigs; ci++) {
-			render_contig(v, ci, ev_begin[ci], ev_begin[ci + 1], o);
+		for (uint32_t u = 0; u < n_units; u++) {
+			render_unit(u, o);
 			if (o.rc) {
 				return o.rc;
 			}
@@ -776,30 +815,30 @@ render_batch(
 		return 0;
 	}
 
-	// workers render contigs (claimed in input order) into a ring of slots; this thread
+	// workers render units (claimed in input order) into a ring of slots; this thread
 	// writes slot after slot, in input order
 	const uint32_t W = 2 * T + 2;
 	std::vector<ContigOut> slots(W);
-	std::atomic<uint32_t> next_ci(0);
+	std::atomic<uint32_t> next_u(0);
 	std::mutex mu;
 	std::condition_variable cv_ready, cv_free;
 	uint32_t written = 0;
 	bool abort = false;
 	auto worker = [&]() {
 		for (;;) {
-			const uint32_t ci = next_ci.fetch_add(1);
-			if (ci >= n_contigs) {
+			const uint32_t u = next_u.fetch_add(1);
+			if (u >= n_units) {
 				return;
 			}
 			{
 				std::unique_lock<std::mutex> lk(mu);
-				cv_free.wait(lk, [&]() { return abort || ci < written + W; });
+				cv_free.wait(lk, [&]() { return abort || u < written + W; });
 				if (abort) {
 					return;
 				}
 			}
-			ContigOut& o = slots[ci % W];
-			render_contig(v, ci, ev_begin[ci], ev_begin[ci + 1], o);
+			ContigOut& o = slots[u % W];
+			render_unit(u, o);
 			{
 				std::lock_guard<std::mutex> lk(mu);
 				o.ready = true;
@@ -812,8 +851,8 @@ render_batch(
 		pool.emplace_back(worker);
 	}
 	int rc = 0;
-	for (uint32_t ci = 0; ci < n_contigs; ci++) {
-		ContigOut& o = slots[ci % W];
+	for (uint32_t u = 0; u < n_units; u++) {
+		ContigOut& o = slots[u % W];
 		{
 			std::unique_lock<std::mutex> lk(mu);
 			cv_ready.wait(lk, [&]() { return o.ready; });
@@ -828,7 +867,7 @@ render_batch(
 		{
 			std::lock_guard<std::mutex> lk(mu);
 			o.ready = false;
-			written = ci + 1;
+			written = u + 1;
 		}
 		cv_free.notify_all();
 	}

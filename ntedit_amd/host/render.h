@@ -28,7 +28,8 @@ struct RenderOptions
 {
 	bool snv = false;               // -s 1: "no edit" substitution records go to the VCF only
 	const Annotations* annot = nullptr;
-	unsigned threads = 0;           // contigs rendered concurrently (0 = up to 8, 1 = in the calling thread)
+	unsigned threads = 0;           // work units rendered concurrently (0 = up to 8, 1 = in the calling thread)
+	unsigned unit_bases = 1u << 20; // a work unit = consecutive contigs of about this many bases
 };
 
 // arena:    host copy of the chunk arena

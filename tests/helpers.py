@@ -460,3 +460,25 @@ def make_tail_case(tmp, k=31):
     ]
     write_fasta(os.path.join(tmp, "draft.fa"), draft, width=60)
     return {"draft": os.path.join(tmp, "draft.fa"), "bf": os.path.join(tmp, "t.bf"), "rep": None}
+
+
+def make_many_case(tmp, n_contigs=3000, mean_len=500, seed=7):
+    """Fragmented-assembly shape: thousands of short contigs cut from one truth genome, with errors, some
+    lowercase stretches and Ns (several renderer work units, events in most contigs)."""
+    os.makedirs(tmp, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    truth = random_genome(rng, 400000)
+    write_fasta(os.path.join(tmp, "truth.fa"), [(b"t", truth)])
+    mkbf([os.path.join(tmp, "truth.fa")], os.path.join(tmp, "t.bf"), k=25, hashes=3, nbytes=1 << 20)
+    draft = []
+    for i in range(n_contigs):
+        L = int(rng.integers(mean_len // 3, mean_len * 2))
+        st = int(rng.integers(0, len(truth) - L))
+        d = bytearray(mutate(rng, truth[st:st + L], 4e-3, 6e-4, 6e-4))
+        if i % 7 == 0 and len(d) > 120:
+            d[40:90] = bytes(d[40:90]).lower()
+        if i % 11 == 0 and len(d) > 200:
+            d[150:153] = b"NNN"
+        draft.append((b"frag%d" % i if i % 3 else b"frag%d note" % i, bytes(d)))
+    write_fasta(os.path.join(tmp, "draft.fa"), draft, width=0)
+    return {"draft": os.path.join(tmp, "draft.fa"), "bf": os.path.join(tmp, "t.bf"), "rep": None}

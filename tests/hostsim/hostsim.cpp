@@ -265,6 +265,9 @@ hostsim_polish(
 	if (const char* rt = getenv("HOSTSIM_RENDER_THREADS")) {
 		ropt.threads = (unsigned)atoi(rt);
 	}
+	// tests: one contig per work unit unless told otherwise, so that the few-contig cases still go through
+	// the concurrent renderer
+	ropt.unit_bases = getenv("HOSTSIM_RENDER_UNIT") ? (unsigned)atoi(getenv("HOSTSIM_RENDER_UNIT")) : 1;
 	ropt.snv = hp->snv != 0;
 	nte_host::Annotations* ann = annot_path ? nte_host::annotations_load(annot_path) : nullptr;
 	ropt.annot = ann;

@@ -114,3 +114,20 @@ def test_last_kmer_is_never_a_seed(tmp_path, oracle_build, kw):
     for suf in ("_changes.tsv", "_edited.fa"):
         assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("h" + suf)), shallow=False), suf
     assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))
+
+
+@pytest.mark.parametrize("unit,threads,kw", [(1 << 20, 4, dict()), (20000, 3, dict(mask=1)), (1 << 20, 1, dict(mode=1)),
+                                             (5000, 8, dict(snv=1))])
+def test_many_short_contigs(tmp_path, oracle_build, monkeypatch, unit, threads, kw):
+    """thousands of contigs: the renderer works in units of consecutive contigs, concurrently, and writes them
+    in input order"""
+    monkeypatch.setenv("HOSTSIM_RENDER_UNIT", str(unit))
+    monkeypatch.setenv("HOSTSIM_RENDER_THREADS", str(threads))
+    case = H.make_many_case(str(tmp_path), n_contigs=600 if kw.get("snv") else 3000)
+    hp = H.default_params(min_contig_len=100, **kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"))
+    rc, nev, nap = H.run_hostsim(H.read_fasta(case["draft"]), H.load_bf(case["bf"]), hp, str(tmp_path / "h"))
+    assert rc == 0 and nap > 100
+    for suf in ("_changes.tsv", "_edited.fa"):
+        assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("h" + suf)), shallow=False), suf
+    assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))

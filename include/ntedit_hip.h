@@ -147,7 +147,7 @@ int ntedit_hip_polish_batch(
     uint32_t n_contigs,
     int on_device,
     ntedit_hip_result** out);
-void ntedit_hip_result_free(ntedit_hip_result* r);
+void ntedit_hip_result_free(ntedit_hip_result* r); /* (also legal after the context was destroyed) */
 
 typedef struct ntedit_hip_stats
 {

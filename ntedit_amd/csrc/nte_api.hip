@@ -43,6 +43,23 @@ struct DevFilter
 // page-locked host buffer (D2H at PCIe speed, no zero-fill); recycled through the context
 static std::atomic<unsigned> g_host_threads(0); // ntedit_hip_set_host_threads()
 
+// contexts that are alive: a result that outlives its context (a garbage-collected binding may free them in
+// any order) must not hand its buffers back to a pool that is gone
+static std::mutex g_live_mu;
+static std::vector<const void*> g_live_ctx;
+
+static bool
+ctx_alive(const void* c)
+{
+	std::lock_guard<std::mutex> lk(g_live_mu);
+	for (const void* p : g_live_ctx) {
+		if (p == c) {
+			return true;
+		}
+	}
+	return false;
+}
+
 struct PinBuf
 {
 	void* p = nullptr;
@@ -165,7 +182,7 @@ pin_give(ntedit_hip_ctx* c, PinBuf& b)
 	if (!b.p) {
 		return;
 	}
-	if (c) {
+	if (c && ctx_alive(c)) {
 		std::lock_guard<std::mutex> lk(c->pin_mu);
 		c->pin_pool.push_back(b);
 	} else {
@@ -591,6 +608,10 @@ ntedit_hip_create(int device, ntedit_hip_ctx** out)
 			return NTEDIT_E_DEVICE;
 		}
 	}
+	{
+		std::lock_guard<std::mutex> lk(g_live_mu);
+		g_live_ctx.push_back(c);
+	}
 	*out = c;
 	return 0;
 }
@@ -600,6 +621,15 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 {
 	if (!c) {
 		return;
+	}
+	{
+		std::lock_guard<std::mutex> lk(g_live_mu);
+		for (size_t i = 0; i < g_live_ctx.size(); i++) {
+			if (g_live_ctx[i] == c) {
+				g_live_ctx.erase(g_live_ctx.begin() + (long)i);
+				break;
+			}
+		}
 	}
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
@@ -1517,7 +1547,7 @@ ntedit_hip_result_free(ntedit_hip_result* r)
 	if (!r) {
 		return;
 	}
-	// results must be freed before their context is destroyed
+	// (a result may outlive its context: its pinned buffers are then released directly)
 	pin_give(r->owner, r->arena_buf);
 	pin_give(r->owner, r->first_buf);
 	delete r;

@@ -46,8 +46,9 @@ def pack_batch(records, min_contig_len=0):
 
 
 class Result:
-    def __init__(self, lib, handle):
+    def __init__(self, lib, handle, owner=None):
         self._lib, self._h = lib, handle
+        self._owner = owner  # keeps the Polisher (and its context) alive as long as the result is
 
     def stats(self):
         s = Stats()
@@ -191,7 +192,7 @@ class Polisher:
                                                    lens.ctypes.data_as(ctypes.c_void_p), len(lens), 0,
                                                    ctypes.byref(res))
         self._check(rc, "polish_batch")
-        return Result(self._lib, res)
+        return Result(self._lib, res, self)
 
     def write_tsv_header(self, tsv_path):
         """header line of _changes.tsv for the loaded primary filter / current parameters"""

@@ -499,3 +499,37 @@ def test_full_size_deep_search_secondary(tmp_path, oracle_build, capsys):
         assert sum(len(v) for v in exp_tsv.values()) > 100
     finally:
         pol.close()
+
+
+def test_cli_edge_inputs(tmp_path, oracle_build):
+    """`ntedit` on inputs at the edges: empty file, only contigs below -z, a contig shorter than k, FASTQ,
+    CRLF line ends, blank lines -- same files as the oracle's command line (which reads with its own reader)"""
+    import subprocess
+    cli = os.path.join(H.ROOT, "ntedit_amd", "ntedit")
+    rng = np.random.default_rng(17)
+    truth = H.random_genome(rng, 30000)
+    H.write_fasta(str(tmp_path / "truth.fa"), [(b"t", truth)])
+    H.mkbf([str(tmp_path / "truth.fa")], str(tmp_path / "t.bf"), k=25, hashes=3, nbytes=1 << 16)
+    d1 = H.mutate(rng, truth[1000:9000], 3e-3, 3e-4, 3e-4)
+    d2 = H.mutate(rng, truth[12000:12600], 3e-3, 0, 0)
+    inputs = {
+        "empty.fa": b"",
+        "short_only.fa": b">a\nACGTACGTACGT\n>b x\nACGT\n",
+        "below_k.fa": b">tiny\nACGTACGTACGTACGTACGT\n>ok\n" + d2 + b"\n",
+        "reads.fq": b"@r1 first\n" + d1 + b"\n+\n" + b"I" * len(d1) + b"\n@r2\n" + d2 + b"\n+r2\n" + b"#" * len(d2) + b"\n",
+        "crlf.fa": b">c1 windows\r\n" + b"\r\n".join(d1[i:i + 60] for i in range(0, len(d1), 60)) + b"\r\n>c2\r\n" + d2 + b"\r\n",
+        "blank_lines.fa": b"\n\n>c1\n" + d1[:4000] + b"\n\n" + d1[4000:] + b"\n\n\n>c2\n\n" + d2 + b"\n",
+    }
+    for name, data in inputs.items():
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            f.write(data)
+        for z in ("0", "100"):
+            o = subprocess.run([os.path.join(H.ORACLE_BUILD, "ntedit_oracle"), "-f", path, "-r", str(tmp_path / "t.bf"), "-b",
+                                str(tmp_path / "o"), "-z", z], capture_output=True, text=True)
+            g = subprocess.run([cli, "-f", path, "-r", str(tmp_path / "t.bf"), "-b", str(tmp_path / "g"), "-z", z],
+                               capture_output=True, text=True)
+            assert o.returncode == 0 and g.returncode == 0, (name, z, o.stderr, g.stderr)
+            for suf in ("_changes.tsv", "_edited.fa"):
+                assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("g" + suf)), shallow=False), (name, z, suf)
+            assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "g_variants.vcf")), (name, z)

@@ -91,7 +91,7 @@ def test_saturated_filter_chains(tmp_path, oracle_build):
     """A saturated filter (h=1, ~50 % of the bits set) with a low acceptance bar: the serial run chains edit
     after edit and hardly ever returns to a clean state, so nearly every speculative event would walk to
     the end of its contig.  The launch budget parks them; the resolver re-runs the applied ones.  Found by
-    tools/fuzz_parity.py (seed 200059)."""
+    tests/tools/fuzz_parity.py (seed 200059)."""
     case = H.make_case(str(tmp_path), 200059, n=27022, contigs=2, k=40, hashes=1, p_sub=0.01, p_ins=0.0, p_del=0.002,
                        flavor="iupac sec", bfbytes=54390)
     kw = dict(max_insertions=4, max_deletions=0, min_contig_len=41, missing_threshold=9.0, edit_threshold=25.0)

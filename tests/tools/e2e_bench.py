@@ -1,14 +1,15 @@
-"""End-to-end region of SURVEY.md 8(d): the `ntedit` host binary from FASTA on disk to
+"""TEST INFRASTRUCTURE (runs the CPU oracle as the checker; lives under tests/ for that reason).
+End-to-end region of SURVEY.md 8(d): the `ntedit` host binary from FASTA on disk to
 _edited.fa/_changes.tsv on disk (reference: "reading/processing input sequence" ->
 "process complete", ntedit.cpp:2589-2598), next to the kernel region it contains.
-usage (GPU box): python tools/e2e_bench.py [bases] [workdir]"""
+usage (GPU box): python tests/tools/e2e_bench.py [bases] [workdir]"""
 import json
 import os
 import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402

@@ -1,7 +1,8 @@
-"""Randomised parity hunt: random cases x random parameters, the oracle against
+"""TEST INFRASTRUCTURE (runs the CPU oracle as the checker; lives under tests/ for that reason).
+Randomised parity hunt: random cases x random parameters, the oracle against
   * the host build of the event-machine logic (default; runs anywhere), or
   * the `ntedit` binary on a GPU (--gpu).
-usage: python tools/fuzz_parity.py [--gpu] [--iters N] [--seed S] [--minutes M] [--keep DIR]
+usage: python tests/tools/fuzz_parity.py [--gpu] [--iters N] [--seed S] [--minutes M] [--keep DIR]
 Prints one line per mismatch (and keeps the case directory); exit code 1 if any."""
 import argparse
 import filecmp
@@ -12,7 +13,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ctypes  # noqa: E402

@@ -1,11 +1,12 @@
-"""Fragmented-assembly shape: very many short contigs (default 500,000 x ~600 bp) through the `ntedit`
-binary, outputs compared with the oracle's CLI.  usage (GPU box): python tools/many_contigs_check.py [n] [len]"""
+"""TEST INFRASTRUCTURE (runs the CPU oracle as the checker; lives under tests/ for that reason).
+Fragmented-assembly shape: very many short contigs (default 500,000 x ~600 bp) through the `ntedit`
+binary, outputs compared with the oracle's CLI.  usage (GPU box): python tests/tools/many_contigs_check.py [n] [len]"""
 import os
 import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402

@@ -86,15 +86,20 @@ class SyntheticJob:
 
     def __init__(self, polisher, total_bases, k=25, hash_num=3, filter_bytes=1 << 32, seed=20251031,
                  draft_seed=None, device="cuda", build_filter="alloc", n_runs=True, mutate=True,
-                 rep_filter_bytes=0, rep_fraction=0.01):
+                 rep_filter_bytes=0, rep_fraction=0.01, contig_len=0):
         """build_filter: "alloc" = allocate a filter in the library and fill it; "insert" = fill the
         filter the polisher already has (e.g. a shared tensor); False = leave the filter alone.
         mutate=False keeps the draft identical to the truth genome (every k-mer is in the filter).
         rep_filter_bytes > 0 also builds a SECONDARY ("repeat", -e) filter holding the k-mers of the first
-        rep_fraction of every truth contig."""
+        rep_fraction of every truth contig.
+        contig_len > 0: contigs of exactly that many truth bases (BASELINE.json configs[2]: 2,500 x 100 kbp)
+        instead of the log-uniform 50 kbp - 50 Mbp mix."""
         self.total_bases = int(total_bases)
         dev = torch.device(device)
-        lens = contig_lengths(total_bases, seed)
+        if contig_len:
+            lens = [int(contig_len)] * max(1, int(total_bases) // int(contig_len))
+        else:
+            lens = contig_lengths(total_bases, seed)
         gen_t = torch.Generator(device=dev)
         gen_t.manual_seed(seed)
         gen_d = torch.Generator(device=dev)

@@ -2476,21 +2476,35 @@ ora_polish_batch_flat(
 }
 
 
-/* ------------------------------------------------------------------ timing driver
+/* ------------------------------------------------------------------ multi-threaded driver
  * The reference parallelises across contigs only (OpenMP loop, ntedit.cpp:2213-2253: every thread
- * takes the next record under a critical section and polishes it).  Same scheme with pthreads, for
- * the cpu_baseline leg of bench.py: nothing is written, the return value is the bases polished. */
+ * takes the next record under a critical section and polishes it).  Same scheme with pthreads.
+ * Two users: the cpu_baseline leg of bench.py (nothing written, contigs handed out in input order like
+ * the reference) and the full-size parity tests (ora_polish_batch_flat_mt_files: every contig's
+ * _edited.fa record / _changes.tsv rows / _variants.vcf rows are kept in memory and written in INPUT
+ * order once all threads are done, i.e. the files of the reference at -t 1). */
 #include <pthread.h>
+
+typedef struct
+{
+	char* p;
+	size_t n;
+} mt_buf;
 
 typedef struct
 {
 	const char* bases;
 	const uint64_t* offsets;
 	const uint32_t* lens;
+	const char* const* names;
 	uint32_t n_contigs;
 	const ora_params* p;
 	const ora_bf* bf;
 	const ora_bf* rep;
+	const uint32_t* order; /* hand-out order (NULL = input order) */
+	mt_buf* fa;            /* per contig, NULL = discard */
+	mt_buf* tsv;
+	mt_buf* vcf;
 	uint32_t next; /* next contig to hand out */
 	uint64_t total;
 	pthread_mutex_t mu;
@@ -2502,20 +2516,64 @@ mt_worker(void* arg)
 	mt_job* j = (mt_job*)arg;
 	for (;;) {
 		pthread_mutex_lock(&j->mu);
-		const uint32_t i = j->next < j->n_contigs ? j->next++ : UINT32_MAX;
+		uint32_t i = j->next < j->n_contigs ? j->next++ : UINT32_MAX;
 		pthread_mutex_unlock(&j->mu);
 		if (i == UINT32_MAX) {
 			return NULL;
 		}
+		if (j->order) {
+			i = j->order[i];
+		}
 		char* seq = (char*)malloc((size_t)j->lens[i] + 1);
 		memcpy(seq, j->bases + j->offsets[i], j->lens[i]);
 		seq[j->lens[i]] = 0;
-		ora_polish_contig("c", seq, j->lens[i], j->p, j->bf, j->rep, NULL, NULL);
+		FILE* fa = j->fa ? open_memstream(&j->fa[i].p, &j->fa[i].n) : NULL;
+		FILE* tsv = j->tsv ? open_memstream(&j->tsv[i].p, &j->tsv[i].n) : NULL;
+		FILE* vcf = j->vcf ? open_memstream(&j->vcf[i].p, &j->vcf[i].n) : NULL;
+		ora_polish_contig_vcf(j->names ? j->names[i] : "c", seq, j->lens[i], j->p, j->bf, j->rep, fa, tsv, vcf, NULL);
+		if (fa) {
+			fclose(fa);
+		}
+		if (tsv) {
+			fclose(tsv);
+		}
+		if (vcf) {
+			fclose(vcf);
+		}
 		free(seq);
 		pthread_mutex_lock(&j->mu);
 		j->total += j->lens[i];
 		pthread_mutex_unlock(&j->mu);
 	}
+}
+
+static void
+mt_run(mt_job* j, unsigned n_threads)
+{
+	pthread_mutex_init(&j->mu, NULL);
+	if (n_threads < 1) {
+		n_threads = 1;
+	}
+	pthread_t* th = (pthread_t*)calloc(n_threads, sizeof(pthread_t));
+	for (unsigned t = 0; t < n_threads; t++) {
+		pthread_create(&th[t], NULL, mt_worker, j);
+	}
+	for (unsigned t = 0; t < n_threads; t++) {
+		pthread_join(th[t], NULL);
+	}
+	free(th);
+	pthread_mutex_destroy(&j->mu);
+}
+
+static void
+flat_bf(ora_bf* bf, const uint8_t* data, uint64_t bytes, unsigned hash_num, unsigned k)
+{
+	memset(bf, 0, sizeof *bf);
+	bf->data = (uint8_t*)data;
+	bf->bytes = bytes;
+	bf->bits = bytes * 8;
+	bf->hash_num = hash_num;
+	bf->k = k;
 }
 
 uint64_t
@@ -2532,12 +2590,7 @@ ora_polish_batch_flat_mt(
     unsigned n_threads)
 {
 	ora_bf bf;
-	memset(&bf, 0, sizeof bf);
-	bf.data = (uint8_t*)bf_data;
-	bf.bytes = bf_bytes;
-	bf.bits = bf_bytes * 8;
-	bf.hash_num = hash_num;
-	bf.k = k;
+	flat_bf(&bf, bf_data, bf_bytes, hash_num, k);
 	ora_params p = *params;
 	p.secbf = 0;
 	ora_params_finalize(&p, &bf);
@@ -2549,18 +2602,94 @@ ora_polish_batch_flat_mt(
 	j.n_contigs = n_contigs;
 	j.p = &p;
 	j.bf = &bf;
-	pthread_mutex_init(&j.mu, NULL);
-	if (n_threads < 1) {
-		n_threads = 1;
+	mt_run(&j, n_threads);
+	return j.total;
+}
+
+static const uint32_t* mt_sort_lens;
+
+static int
+mt_by_len_desc(const void* a, const void* b)
+{
+	const uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+	if (mt_sort_lens[x] != mt_sort_lens[y]) {
+		return mt_sort_lens[x] > mt_sort_lens[y] ? -1 : 1;
 	}
-	pthread_t* th = (pthread_t*)calloc(n_threads, sizeof(pthread_t));
-	for (unsigned t = 0; t < n_threads; t++) {
-		pthread_create(&th[t], NULL, mt_worker, &j);
+	return x < y ? -1 : (x > y);
+}
+
+uint64_t
+ora_polish_batch_flat_mt_files(
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    const uint8_t* bf_data,
+    uint64_t bf_bytes,
+    unsigned hash_num,
+    unsigned k,
+    const uint8_t* rep_data,
+    uint64_t rep_bytes,
+    unsigned rep_hash_num,
+    const ora_params* params,
+    unsigned n_threads,
+    const char* fa_path,
+    const char* tsv_path,
+    const char* vcf_path)
+{
+	ora_bf bf, rep;
+	flat_bf(&bf, bf_data, bf_bytes, hash_num, k);
+	flat_bf(&rep, rep_data, rep_bytes, rep_hash_num, k);
+	ora_params p = *params;
+	p.secbf = rep_data != NULL;
+	ora_params_finalize(&p, &bf);
+	mt_job j;
+	memset(&j, 0, sizeof j);
+	j.bases = bases;
+	j.offsets = offsets;
+	j.lens = lens;
+	j.names = names;
+	j.n_contigs = n_contigs;
+	j.p = &p;
+	j.bf = &bf;
+	j.rep = rep_data ? &rep : NULL;
+	/* longest contig first: the wall time of a checker run should not hang on a 50 Mbp contig
+	 * that happened to come last (the OUTPUT order is the input order either way) */
+	uint32_t* order = (uint32_t*)malloc(((size_t)n_contigs + 1) * sizeof(uint32_t));
+	for (uint32_t i = 0; i < n_contigs; i++) {
+		order[i] = i;
 	}
-	for (unsigned t = 0; t < n_threads; t++) {
-		pthread_join(th[t], NULL);
+	mt_sort_lens = lens;
+	qsort(order, n_contigs, sizeof(uint32_t), mt_by_len_desc);
+	j.order = order;
+	j.fa = fa_path ? (mt_buf*)calloc((size_t)n_contigs + 1, sizeof(mt_buf)) : NULL;
+	j.tsv = tsv_path ? (mt_buf*)calloc((size_t)n_contigs + 1, sizeof(mt_buf)) : NULL;
+	j.vcf = vcf_path ? (mt_buf*)calloc((size_t)n_contigs + 1, sizeof(mt_buf)) : NULL;
+	mt_run(&j, n_threads);
+	free(order);
+	const char* paths[3] = { fa_path, tsv_path, vcf_path };
+	mt_buf* bufs[3] = { j.fa, j.tsv, j.vcf };
+	for (int s = 0; s < 3; s++) {
+		if (!paths[s]) {
+			continue;
+		}
+		FILE* f = fopen(paths[s], "w");
+		if (f) {
+			if (s == 1) {
+				ora_write_tsv_header(f, &p, &bf);
+			}
+			for (uint32_t i = 0; i < n_contigs; i++) {
+				if (bufs[s][i].n) {
+					fwrite(bufs[s][i].p, 1, bufs[s][i].n, f);
+				}
+			}
+			fclose(f);
+		}
+		for (uint32_t i = 0; i < n_contigs; i++) {
+			free(bufs[s][i].p);
+		}
+		free(bufs[s]);
 	}
-	free(th);
-	pthread_mutex_destroy(&j.mu);
 	return j.total;
 }

@@ -181,7 +181,7 @@ uint64_t ora_polish_batch_flat(
     const char* tsv_path);
 
 /* the same, contigs handed out to n_threads worker threads the way the reference's OpenMP loop does
- * (ntedit.cpp:2213-2253); timing only: nothing is written */
+ * (ntedit.cpp:2213-2253, contigs in input order); timing only: nothing is written */
 uint64_t ora_polish_batch_flat_mt(
     const char* bases,
     const uint64_t* offsets,
@@ -193,6 +193,29 @@ uint64_t ora_polish_batch_flat_mt(
     unsigned k,
     const ora_params* params,
     unsigned n_threads);
+
+/* the same scheme with outputs: every contig's _edited.fa record, _changes.tsv rows and _variants.vcf
+ * body rows (no VCF header, no annotations) are buffered and written in INPUT order after the threads
+ * are done = the files of the reference at -t 1.  Contigs are handed out longest first.  Paths may be
+ * NULL; rep_data may be NULL.  Used by the full-size parity tests (every contig of a 3 Gbp batch). */
+uint64_t ora_polish_batch_flat_mt_files(
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    const uint8_t* bf_data,
+    uint64_t bf_bytes,
+    unsigned hash_num,
+    unsigned k,
+    const uint8_t* rep_data,
+    uint64_t rep_bytes,
+    unsigned rep_hash_num,
+    const ora_params* params,
+    unsigned n_threads,
+    const char* fa_path,
+    const char* tsv_path,
+    const char* vcf_path);
 
 /* counters for work-profile checks */
 typedef struct

@@ -140,6 +140,50 @@ def oracle_polish_flat_mt(blob, offsets, lens, bits, hash_num, k, threads):
         ctypes.c_uint(hash_num), ctypes.c_uint(k), ctypes.byref(p), ctypes.c_uint(threads))
 
 
+def oracle_polish_flat_mt_files(blob, offsets, lens, names, bits, hash_num, k, threads, fa_path=None, tsv_path=None,
+                                vcf_path=None, rep_bits=None, rep_hash_num=0, **params):
+    """The oracle over an in-memory batch with contigs handed out to `threads` worker threads; the complete
+    _edited.fa / _changes.tsv / VCF body are written in input order (= ora_polish_batch_flat's files).
+    blob may be bytes or a numpy uint8 array (GB-sized batches: no copy).  Returns the bases polished."""
+    lib = oracle_lib()
+    lib.ora_polish_batch_flat_mt_files.restype = ctypes.c_uint64
+    p = OraParams()
+    lib.ora_params_default(ctypes.byref(p))
+    for name, v in params.items():
+        setattr(p, name, v)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    rep_ptr, rep_n = None, 0
+    if rep_bits is not None:
+        rep_bits = np.ascontiguousarray(rep_bits, dtype=np.uint8)
+        rep_ptr, rep_n = rep_bits.ctypes.data_as(ctypes.c_void_p), rep_bits.size
+    if isinstance(blob, np.ndarray):
+        keep = np.ascontiguousarray(blob, dtype=np.uint8)
+        bptr = ctypes.c_void_p(keep.ctypes.data)
+    else:
+        bptr = ctypes.cast(ctypes.c_char_p(blob), ctypes.c_void_p)
+    arr = (ctypes.c_char_p * max(len(names), 1))(*names)
+    enc = lambda x: x.encode() if x else None  # noqa: E731
+    return lib.ora_polish_batch_flat_mt_files(
+        bptr, offsets.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), arr,
+        ctypes.c_uint32(len(lens)), bits.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bits.size),
+        ctypes.c_uint(hash_num), ctypes.c_uint(k), rep_ptr, ctypes.c_uint64(rep_n), ctypes.c_uint(rep_hash_num),
+        ctypes.byref(p), ctypes.c_uint(threads), enc(fa_path), enc(tsv_path), enc(vcf_path))
+
+
+def usable_cpus():
+    """CPUs this process may use (cgroup quota aware)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 _hostsim = None
 
 

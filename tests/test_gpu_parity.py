@@ -261,35 +261,109 @@ def test_cli_drop_in(tmp_path, oracle_build):
     assert filecmp.cmp(str(tmp_path / "o3_edited.fa"), str(tmp_path / "g2_edited.fa"), shallow=False)
 
 
-def _sample_records(fa_path, tsv_path, want):
-    """FASTA records / TSV rows of the contigs named in `want` (streamed: the files are GB-sized)"""
-    fa, tsv = {}, {w: [] for w in want}
-    with open(fa_path, "rb") as f:
+def _differing_contigs(fa_a, fa_b, tsv_a, tsv_b, limit=5):
+    """(count, first few names) of contigs whose FASTA record or TSV rows differ -- only read on a mismatch
+    (the files are GB-sized: streamed)"""
+    bad = []
+    n_bad = 0
+    with open(fa_a, "rb") as fa, open(fa_b, "rb") as fb:
         while True:
-            hdr = f.readline()
-            if not hdr:
+            ha, hb = fa.readline(), fb.readline()
+            if not ha and not hb:
                 break
-            seq = f.readline()
-            name = hdr[1:].split()[0]
-            if name in tsv:
-                fa[name] = (hdr, seq)
-    with open(tsv_path, "rb") as f:
-        f.readline()
-        for line in f:
-            name = line.split(b"\t", 1)[0]
-            if name in tsv:
-                tsv[name].append(line)
-    return fa, tsv
+            sa, sb = fa.readline(), fb.readline()
+            if ha != hb or sa != sb:
+                n_bad += 1
+                if len(bad) < limit:
+                    bad.append((ha[:40] or hb[:40]).decode(errors="replace").strip())
+
+    def rows(path):
+        d = {}
+        with open(path, "rb") as f:
+            f.readline()
+            for line in f:
+                d.setdefault(line.split(b"\t", 1)[0], []).append(line)
+        return d
+    ra, rb = rows(tsv_a), rows(tsv_b)
+    for name in set(ra) | set(rb):
+        if ra.get(name) != rb.get(name):
+            n_bad += 1
+            if len(bad) < limit:
+                bad.append("tsv:" + name.decode(errors="replace"))
+    return n_bad, bad
 
 
-def test_full_size_properties(tmp_path, oracle_build):
-    """BASELINE.json's full configuration (3 Gbp draft, k=25, 4 GiB filter), where the oracle cannot
-    run the whole job: size-independent properties plus an oracle spot check.
+def _compare_every_contig(pol, job, tmp_path, tag, capsys, rep=False, **kw):
+    """Polish the whole HBM-resident batch on the GPU, render ALL of it, run the multi-threaded oracle on ALL
+    of it with the same filter(s) (downloaded from HBM), and compare the complete _edited.fa, _changes.tsv and
+    VCF body byte for byte: every contig of the batch, 0 differences allowed.  Returns the GPU stats."""
+    import time
+    nc = len(job.lens)
+    names = [b"contig%d" % i for i in range(nc)]
+    t0 = time.time()
+    res = pol.polish_batch(None, job.offsets, job.lens, device_ptr=job.device_ptr, n=job.n_bytes)
+    host = job.batch.cpu().numpy()
+    fa, tsv, vcf = (str(tmp_path / (tag + s)) for s in ("_edited.fa", "_changes.tsv", "_variants.vcf"))
+    pol.write_tsv_header(tsv)
+    open(vcf, "wb").close()
+    res.write(host, job.offsets, job.lens, names, fa, tsv, append=True, vcf_path=vcf)
+    st = res.stats()
+    res.free()
+    t_gpu = time.time() - t0
+    bits = pol.filter_download(0)
+    rbits = pol.filter_download(1) if rep else None
+    k, h, _, _ = pol.filter_info(0)
+    ofa, otsv, ovcf = (str(tmp_path / (tag + s)) for s in ("_ora_edited.fa", "_ora_changes.tsv", "_ora_body.vcf"))
+    threads = H.usable_cpus()
+    t0 = time.time()
+    done = H.oracle_polish_flat_mt_files(host, job.offsets, job.lens, names, bits, h, k, threads, fa_path=ofa,
+                                         tsv_path=otsv, vcf_path=ovcf, rep_bits=rbits, rep_hash_num=h, **kw)
+    t_ora = time.time() - t0
+    assert done == job.n_bases
+    same = (filecmp.cmp(fa, ofa, shallow=False), filecmp.cmp(tsv, otsv, shallow=False),
+            filecmp.cmp(vcf, ovcf, shallow=False))
+    with capsys.disabled():
+        print("\n[%s] %d contigs, %.0f Mbases: GPU step %.1f ms (%.0f Mbases/s; screen %.1f ms, machine %.1f ms), "
+              "GPU+render %.1f s, oracle on %d threads %.1f s (%.1f Mbases/s); %d subs %d ins %d del; files identical: %s"
+              % (tag, nc, job.n_bases / 1e6, st.ms_total, job.n_bases / st.ms_total / 1e3, st.ms_screen, st.ms_machine,
+                 t_gpu, threads, t_ora, job.n_bases / t_ora / 1e6, st.substitutions, st.insertions, st.deletions,
+                 same), flush=True)
+    if not all(same):
+        n_bad, bad = _differing_contigs(fa, ofa, tsv, otsv)
+        raise AssertionError("%s: %d contig(s) differ from the oracle, e.g. %s (vcf identical: %s)" %
+                             (tag, n_bad, bad, same[2]))
+    assert os.path.getsize(tsv) > 1000
+    for f in (ofa, otsv, ovcf, fa):  # (GB-sized: do not keep them for pytest's tmp_path retention)
+        os.remove(f)
+    return st, host, names
+
+
+def _partition_independence(pol, job, host, names, whole):
+    """the per-kind edit counts of the whole batch equal the sum over a 2-way split of its contigs"""
+    import torch
+    nc = len(job.lens)
+    parts = []
+    for lo, hi in ((0, nc // 2), (nc // 2, nc)):
+        o0 = int(job.offsets[lo])
+        o1 = int(job.offsets[hi - 1]) + int(job.lens[hi - 1]) + 1
+        offs_h = job.offsets[lo:hi] - np.uint64(o0)
+        half = job.batch[o0:o1].clone()  # (device batches have to start 16-byte aligned)
+        torch.cuda.synchronize()
+        r = pol.polish_batch(None, offs_h, job.lens[lo:hi], device_ptr=half.data_ptr(), n=o1 - o0)
+        del half
+        r.write(host[o0:o1], offs_h, job.lens[lo:hi], names[lo:hi], None, None)
+        s = r.stats()
+        parts.append((s.absent_kmers, s.substitutions, s.insertions, s.deletions))
+        r.free()
+    assert tuple(a + b for a, b in zip(*parts)) == whole
+
+
+def test_full_size_every_contig(tmp_path, oracle_build, capsys):
+    """BASELINE.json configs[3] at full size (3 Gbp draft, 369 contigs 50 kbp - 50 Mbp, k=25, 4 GiB filter):
       1. no false negatives: an unmutated draft has no absent k-mer and gets no edit;
-      2. partition independence: the per-kind edit counts of the whole batch equal the sum over a
-         2-way split of its contigs;
-      3. three contigs (shortest, 1/8 quantile, median length) picked from the full-batch result are byte-identical to the oracle's output
-         for them (same 4 GiB filter, downloaded from HBM)."""
+      2. EVERY contig of the batch is byte-identical to the oracle's output (complete _edited.fa, _changes.tsv and
+         VCF body; the oracle runs the whole 3 Gbp on all host cores with the same 4 GiB filter);
+      3. partition independence: the per-kind edit counts of the whole batch equal the sum over a 2-way split."""
     import torch
     import ntedit_amd
     from ntedit_amd.synth import SyntheticJob
@@ -308,64 +382,34 @@ def test_full_size_properties(tmp_path, oracle_build):
         res.free()
         del job
         torch.cuda.empty_cache()
-
-        # the mutated draft of the same genome (the filter is already built)
+        # 2. the mutated draft of the same genome (the filter is already built)
         job = SyntheticJob(pol, total, k=25, hash_num=3, filter_bytes=fbytes, build_filter=False)
-        res = pol.polish_batch(None, job.offsets, job.lens, device_ptr=job.device_ptr, n=job.n_bytes)
-        # render the whole batch (the per-kind edit counts are produced by the renderer)
-        nc = len(job.lens)
-        names = [b"contig%d" % i for i in range(nc)]
-        host = job.batch.cpu().numpy()
-        fa, tsv = str(tmp_path / "full_edited.fa"), str(tmp_path / "full_changes.tsv")
-        pol.write_tsv_header(tsv)
-        res.write(host, job.offsets, job.lens, names, fa, tsv, append=True)
-        st = res.stats()
-        res.free()
-        whole = (st.absent_kmers, st.substitutions, st.insertions, st.deletions)  # (event counts depend on the grid)
+        st, host, names = _compare_every_contig(pol, job, tmp_path, "configs3", capsys)
         assert st.insertions > 0 and st.deletions > 0
         # the synthetic error rates: 0.1% substitutions, 0.01% indels -- nearly all are repaired
         assert 0.8e-3 * job.n_bases < st.substitutions < 1.2e-3 * job.n_bases
+        # 3.
+        _partition_independence(pol, job, host, names,
+                                (st.absent_kmers, st.substitutions, st.insertions, st.deletions))
+    finally:
+        pol.close()
 
-        # 2. two halves, polished and rendered (to nowhere) separately
-        parts = []
-        for lo, hi in ((0, nc // 2), (nc // 2, nc)):
-            o0 = int(job.offsets[lo])
-            o1 = int(job.offsets[hi - 1]) + int(job.lens[hi - 1]) + 1
-            offs_h = job.offsets[lo:hi] - np.uint64(o0)
-            half = job.batch[o0:o1].clone()  # (device batches have to start 16-byte aligned)
-            torch.cuda.synchronize()
-            r = pol.polish_batch(None, offs_h, job.lens[lo:hi], device_ptr=half.data_ptr(), n=o1 - o0)
-            del half
-            r.write(host[o0:o1], offs_h, job.lens[lo:hi], names[lo:hi], None, None)
-            s = r.stats()
-            parts.append((s.absent_kmers, s.substitutions, s.insertions, s.deletions))
-            r.free()
-        assert tuple(a + b for a, b in zip(*parts)) == whole
 
-        # 3. compare a sample of contigs with the oracle
-        order = np.argsort(job.lens, kind="stable")
-        pick = sorted({int(order[0]), int(order[len(order) // 8]), int(order[len(order) // 2])})
-        blob, offs, lens, pos = [], [], [], 0
-        for i in pick:
-            o, l = int(job.offsets[i]), int(job.lens[i])
-            blob.append(host[o:o + l + 1].tobytes())
-            offs.append(pos)
-            lens.append(l)
-            pos += l + 1
-        bits = pol.filter_download(0)
-        k, h, nbytes, _ = pol.filter_info(0)
-        ofa, otsv = str(tmp_path / "ora_edited.fa"), str(tmp_path / "ora_changes.tsv")
-        done = H.oracle_polish_flat(b"".join(blob), offs, lens, bits, h, k, names=[names[i] for i in pick],
-                                    fa_path=ofa, tsv_path=otsv)
-        assert done == sum(lens)
-        want = [names[i] for i in pick]
-        got_fa, got_tsv = _sample_records(fa, tsv, want)
-        exp_fa, exp_tsv = _sample_records(ofa, otsv, want)
-        assert set(got_fa) == set(want) == set(exp_fa)
-        for w in want:
-            assert got_fa[w] == exp_fa[w], w
-            assert got_tsv[w] == exp_tsv[w], w
-        assert sum(len(v) for v in exp_tsv.values()) > 100
+def test_config2_250mbp_every_contig(tmp_path, oracle_build, capsys):
+    """BASELINE.json configs[2]: synthetic 250 Mbp draft of 2,500 x 100 kbp contigs (0.1% mismatches + 0.01% indels),
+    k=25, 4 GiB filter, one MI355X -- every contig byte-identical to the oracle."""
+    import ntedit_amd
+    from ntedit_amd.synth import SyntheticJob
+
+    fbytes = int(os.environ.get("NTEDIT_FULL_FILTER", str(1 << 32)))
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.set_params(ntedit_amd.default_params())
+        job = SyntheticJob(pol, 250e6, k=25, hash_num=3, filter_bytes=fbytes, contig_len=100_000, n_runs=False)
+        assert len(job.lens) == 2500
+        st, host, names = _compare_every_contig(pol, job, tmp_path, "configs2", capsys)
+        assert 0.8e-3 * job.n_bases < st.substitutions < 1.2e-3 * job.n_bases
+        assert st.insertions > 0 and st.deletions > 0
     finally:
         pol.close()
 
@@ -430,9 +474,8 @@ def test_last_kmer_is_never_a_seed_gpu(tmp_path, oracle_build, kw):
 
 def test_full_size_deep_search_secondary(tmp_path, oracle_build, capsys):
     """BASELINE.json configs[4] at full size: 3 Gbp draft, k=35, primary + secondary ("repeat", -e) 4 GiB
-    filters, -i 5 -d 9 (after the reference's clamp of -i 9).  Partition independence of the edit counts and
-    an oracle spot check of contigs rendered from the full batch."""
-    import torch
+    filters, -i 5 -d 9 (after the reference's clamp of -i 9).  EVERY contig byte-identical to the oracle run on the
+    whole batch with both filters, plus partition independence of the edit counts."""
     import ntedit_amd
     from ntedit_amd.synth import SyntheticJob
 
@@ -445,58 +488,10 @@ def test_full_size_deep_search_secondary(tmp_path, oracle_build, capsys):
         pol.set_params(ntedit_amd.default_params(**kw))
         res = pol.polish_batch(None, job.offsets, job.lens, device_ptr=job.device_ptr, n=job.n_bytes)
         res.free()  # (warm-up: buffers)
-        res = pol.polish_batch(None, job.offsets, job.lens, device_ptr=job.device_ptr, n=job.n_bytes)
-        nc = len(job.lens)
-        names = [b"contig%d" % i for i in range(nc)]
-        host = job.batch.cpu().numpy()
-        fa, tsv = str(tmp_path / "full_edited.fa"), str(tmp_path / "full_changes.tsv")
-        pol.write_tsv_header(tsv)
-        res.write(host, job.offsets, job.lens, names, fa, tsv, append=True)
-        st = res.stats()
-        res.free()
-        with capsys.disabled():
-            print("\n[configs[4]] %.0f Mbases in %.1f ms (screen %.1f ms): %.0f Mbases/s; %d subs %d ins %d del" %
-                  (job.n_bases / 1e6, st.ms_total, st.ms_screen, job.n_bases / st.ms_total / 1e3,
-                   st.substitutions, st.insertions, st.deletions))
-        whole = (st.absent_kmers, st.substitutions, st.insertions, st.deletions)  # (event counts depend on the grid)
+        st, host, names = _compare_every_contig(pol, job, tmp_path, "configs4", capsys, rep=True, **kw)
         assert st.substitutions > 0 and st.insertions > 0 and st.deletions > 0
-        parts = []
-        for lo, hi in ((0, nc // 2), (nc // 2, nc)):
-            o0 = int(job.offsets[lo])
-            o1 = int(job.offsets[hi - 1]) + int(job.lens[hi - 1]) + 1
-            offs_h = job.offsets[lo:hi] - np.uint64(o0)
-            half = job.batch[o0:o1].clone()
-            torch.cuda.synchronize()
-            r = pol.polish_batch(None, offs_h, job.lens[lo:hi], device_ptr=half.data_ptr(), n=o1 - o0)
-            del half
-            r.write(host[o0:o1], offs_h, job.lens[lo:hi], names[lo:hi], None, None)
-            s = r.stats()
-            parts.append((s.absent_kmers, s.substitutions, s.insertions, s.deletions))
-            r.free()
-        assert tuple(a + b for a, b in zip(*parts)) == whole
-        order = np.argsort(job.lens, kind="stable")
-        pick = sorted({int(order[0]), int(order[len(order) // 8]), int(order[len(order) // 3])})
-        blob, offs, lens, pos = [], [], [], 0
-        for i in pick:
-            o, l = int(job.offsets[i]), int(job.lens[i])
-            blob.append(host[o:o + l + 1].tobytes())
-            offs.append(pos)
-            lens.append(l)
-            pos += l + 1
-        bits, rep = pol.filter_download(0), pol.filter_download(1)
-        k, h, nbytes, _ = pol.filter_info(0)
-        ofa, otsv = str(tmp_path / "ora_edited.fa"), str(tmp_path / "ora_changes.tsv")
-        done = H.oracle_polish_flat(b"".join(blob), offs, lens, bits, h, k, names=[names[i] for i in pick],
-                                    fa_path=ofa, tsv_path=otsv, rep_bits=rep, rep_hash_num=h, **kw)
-        assert done == sum(lens)
-        want = [names[i] for i in pick]
-        got_fa, got_tsv = _sample_records(fa, tsv, want)
-        exp_fa, exp_tsv = _sample_records(ofa, otsv, want)
-        assert set(got_fa) == set(want) == set(exp_fa)
-        for w in want:
-            assert got_fa[w] == exp_fa[w], w
-            assert got_tsv[w] == exp_tsv[w], w
-        assert sum(len(v) for v in exp_tsv.values()) > 100
+        _partition_independence(pol, job, host, names,
+                                (st.absent_kmers, st.substitutions, st.insertions, st.deletions))
     finally:
         pol.close()
 

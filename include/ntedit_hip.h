@@ -32,12 +32,14 @@ extern "C" {
 #define NTEDIT_E_OVERFLOW (-4) /* internal capacity exceeded after retries */
 #define NTEDIT_E_IO (-5)       /* file could not be read / written         */
 #define NTEDIT_E_UNSUPPORTED (-6) /* operation not available (e.g. GPU build of a counting filter) */
+#define NTEDIT_E_SEGMENT (-7)  /* a contig segment's cut is not event-free (see ntedit_hip_segment)      */
 
 #define NTEDIT_FILTER_PRIMARY 0   /* -r  (ntedit.cpp:2438) */
 #define NTEDIT_FILTER_SECONDARY 1 /* -e  (ntedit.cpp:2570) */
 
 typedef struct ntedit_hip_ctx ntedit_hip_ctx;
 typedef struct ntedit_hip_result ntedit_hip_result;
+typedef struct ntedit_hip_annot ntedit_hip_annot; /* -l annotation map, see ntedit_hip_annot_load() */
 
 /* The opt:: parameter block (ntedit.cpp:99-133).  k and h are taken from the
  * primary filter (ntedit.cpp:2439,2448), not from -k. */
@@ -186,10 +188,10 @@ int ntedit_hip_write_tsv_header(const char* tsv_path, uint32_t k, uint32_t jump,
 
 /* _variants.vcf (ntedit.cpp:951-977, 986-1162, 1184-1208; header 2192-2211) and the -l
  * annotation map (vcf_entry_to_map, ntedit.cpp:2261-2274; plain or gzipped input).
- * write_outputs_vcf = write_outputs + the VCF body; snv = the -s flag the batch was polished
- * with (in SNV mode unedited positions with supported alternatives are VCF-only records);
+ * write_outputs_vcf = write_outputs + the VCF body.  SNV mode (unedited positions with supported
+ * alternatives are VCF-only records, ntedit.cpp:1428-1443) follows the -s flag the batch was POLISHED
+ * with; the `snv` argument is kept for source compatibility and ignored.
  * annot may be NULL (every annotation reads "NA"). */
-typedef struct ntedit_hip_annot ntedit_hip_annot;
 int ntedit_hip_annot_load(const char* vcf_path, ntedit_hip_annot** out);
 void ntedit_hip_annot_free(ntedit_hip_annot* a);
 int ntedit_hip_write_vcf_header(const char* vcf_path, const char* draft_filename);
@@ -206,6 +208,94 @@ int ntedit_hip_write_outputs_vcf(
     int append,
     int snv,
     const ntedit_hip_annot* annot);
+
+/* ---- contigs cut into segments (multi-GPU sharding of contigs larger than a GPU's share) -----------
+ * The reference polishes a contig serially (kmerizeAndCorrect, ntedit.cpp:1747-2151; its only limit is
+ * the 32-bit position, ntedit.cpp:1773-1774), so a single chromosome keeps one OpenMP thread busy while
+ * the others idle.  Here a batch entry may be a SEGMENT [a, c) of a contig, handed over with `halo`
+ * extra draft bases [c, c + halo) behind it as look-ahead room.  The serial run can be cut at c exactly
+ * when it is in its clean state there (both rope cursors in the open position node, window = k untouched
+ * draft bases): from then on its state is a function of the draft alone, and the next segment, polished
+ * anywhere else, starts from the same state.  The caller places c inside a run of k-mers that are all in
+ * the filter (ntedit_amd/dist.py: refine_cut); the library VERIFIES the cut from the edit records --
+ * every applied event ended at or before c and nothing behind c was touched -- and refuses to render
+ * the entry otherwise (NTEDIT_E_SEGMENT; ntedit_hip_result_cover_ends() lets the caller check first and
+ * re-run the segment joined with its successor).  Concatenating the segments' output is then byte-identical to
+ * the unsplit contig's. */
+#define NTEDIT_SEG_NO_HEADER 1u  /* not the first segment of its contig: no ">name" line                  */
+#define NTEDIT_SEG_NO_NEWLINE 2u /* not the last segment: the sequence line stays open                    */
+#define NTEDIT_SEG_SKIP 4u       /* write nothing for this entry (it was superseded by a joined re-run)    */
+typedef struct ntedit_hip_segment
+{
+	uint32_t pos_offset; /* contig position of the entry's first base: added to every reported position */
+	uint32_t halo;       /* trailing bases of the entry that belong to the next segment (not rendered) */
+	uint32_t flags;      /* NTEDIT_SEG_* */
+	uint32_t reserved;
+} ntedit_hip_segment;
+
+/* where the serial run of every entry's last applied event ended (entry-relative position; 0 = the entry
+ * has no applied event).  A segment with a halo is valid iff cover_end <= lens[i] - halo. */
+int ntedit_hip_result_cover_ends(const ntedit_hip_result* r, uint32_t n_contigs, uint32_t* cover_ends);
+
+/* ---- edit records (the reference's per-contig rope + substitution queue, sRec / seqNode,
+ * ntedit.cpp:599-620, flattened the way writeEditsToFile walks them, ntedit.cpp:936-1212) -------------
+ * One record per _changes.tsv row, in file order; in SNV mode (-s 1) positions that keep their base but
+ * have supported alternatives (VCF-only records) come as NTEDIT_EDIT_SNV_KEPT. */
+#define NTEDIT_EDIT_SUB 1
+#define NTEDIT_EDIT_INS 2
+#define NTEDIT_EDIT_DEL 3
+#define NTEDIT_EDIT_SNV_KEPT 4
+typedef struct ntedit_hip_edit
+{
+	uint32_t contig;     /* entry index in the batch                                                      */
+	uint32_t draft_pos;  /* 0-based draft position: SUB the base; INS the base the insertion precedes;
+	                        DEL the first deleted base.  TSV column 2 = draft_pos + 1 (SUB) / draft_pos     */
+	uint32_t bases_off;  /* INS / DEL: offset of the inserted / deleted bases in the pool                   */
+	uint16_t len;        /* INS / DEL: number of bases; SUB: 1                                              */
+	uint16_t support;    /* k-mers supporting the edit (TSV column 5)                                       */
+	uint8_t kind;        /* NTEDIT_EDIT_*                                                                   */
+	uint8_t draft_base;  /* TSV "OriginalBase"                                                              */
+	uint8_t new_base;    /* SUB: the replacement                                                            */
+	uint8_t n_alt;       /* SUB: alternate bases with support > 0                                           */
+	uint8_t alt_base[3];
+	uint8_t alt_support[3];
+	uint8_t reserved[2];
+} ntedit_hip_edit;
+/* Builds (once, cached in the result) and returns the records of the whole batch.  bases/offsets/lens:
+ * the batch in HOST memory, segments: NULL or the descriptors the batch will be rendered with.  The
+ * pointers stay valid until ntedit_hip_result_free(). */
+int ntedit_hip_result_edits(
+    ntedit_hip_result* r,
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    uint32_t n_contigs,
+    const ntedit_hip_segment* segments,
+    const ntedit_hip_edit** edits,
+    uint64_t* n_edits,
+    const char** base_pool);
+
+/* write_outputs with everything optional in one block.  SNV mode is taken from the parameters the batch
+ * was polished with. */
+typedef struct ntedit_hip_write_options
+{
+	const char* fa_path;  /* NULL: skip that stream */
+	const char* tsv_path;
+	const char* vcf_path;
+	int append;
+	const ntedit_hip_annot* annot;      /* -l map or NULL */
+	const ntedit_hip_segment* segments; /* NULL, or one descriptor per entry */
+	uint64_t* out_sizes;                /* NULL, or 3 * n_contigs: bytes every entry appended to fa / tsv / vcf
+	                                       (the index the multi-GPU gather merges by) */
+} ntedit_hip_write_options;
+int ntedit_hip_write_outputs_ex(
+    const ntedit_hip_result* r,
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    const ntedit_hip_write_options* opt);
 
 /* Host threads used by write_outputs() to render contigs concurrently (the reference's -t;
  * output order and bytes do not depend on it).  0 = default (up to 8).  Process-wide.

@@ -57,6 +57,38 @@ class Stats(ctypes.Structure):
     ]
 
 
+class Segment(ctypes.Structure):
+    """ntedit_hip_segment: a batch entry that is one segment of a contig cut for multi-GPU sharding"""
+    _fields_ = [("pos_offset", ctypes.c_uint32), ("halo", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
+
+
+SEG_NO_HEADER, SEG_NO_NEWLINE, SEG_SKIP = 1, 2, 4
+E_SEGMENT = -7
+EDIT_SUB, EDIT_INS, EDIT_DEL, EDIT_SNV_KEPT = 1, 2, 3, 4
+
+
+class Edit(ctypes.Structure):
+    """ntedit_hip_edit: one _changes.tsv row as a POD record"""
+    _fields_ = [("contig", ctypes.c_uint32), ("draft_pos", ctypes.c_uint32), ("bases_off", ctypes.c_uint32),
+                ("len", ctypes.c_uint16), ("support", ctypes.c_uint16), ("kind", ctypes.c_uint8),
+                ("draft_base", ctypes.c_uint8), ("new_base", ctypes.c_uint8), ("n_alt", ctypes.c_uint8),
+                ("alt_base", ctypes.c_uint8 * 3), ("alt_support", ctypes.c_uint8 * 3), ("reserved", ctypes.c_uint8 * 2)]
+
+
+# the same record as a numpy dtype (28 bytes)
+EDIT_DTYPE = [("contig", "<u4"), ("draft_pos", "<u4"), ("bases_off", "<u4"), ("len", "<u2"), ("support", "<u2"),
+              ("kind", "u1"), ("draft_base", "u1"), ("new_base", "u1"), ("n_alt", "u1"), ("alt_base", "u1", (3,)),
+              ("alt_support", "u1", (3,)), ("reserved", "u1", (2,))]
+
+
+class WriteOptions(ctypes.Structure):
+    """ntedit_hip_write_options"""
+    _fields_ = [("fa_path", ctypes.c_char_p), ("tsv_path", ctypes.c_char_p), ("vcf_path", ctypes.c_char_p),
+                ("append", ctypes.c_int), ("annot", ctypes.c_void_p), ("segments", ctypes.c_void_p),
+                ("out_sizes", ctypes.c_void_p)]
+
+
 # every symbol include/ntedit_hip.h declares
 EXPORTS = [
     "ntedit_hip_params_default", "ntedit_hip_params_clamp", "ntedit_hip_create", "ntedit_hip_destroy",
@@ -68,6 +100,7 @@ EXPORTS = [
     "ntedit_hip_write_tsv_header", "ntedit_hip_last_kernel_ms", "ntedit_hip_gather_bench",
     "ntedit_hip_annot_load", "ntedit_hip_annot_free", "ntedit_hip_write_vcf_header", "ntedit_hip_write_outputs_vcf",
     "ntedit_hip_set_host_threads", "ntedit_hip_filter_occupancy",
+    "ntedit_hip_write_outputs_ex", "ntedit_hip_result_cover_ends", "ntedit_hip_result_edits",
 ]
 
 _lib = None
@@ -119,6 +152,11 @@ def load():
     lib.ntedit_hip_write_vcf_header.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     lib.ntedit_hip_write_outputs_vcf.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_char_p), u32,
                                                  ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ci, ci, vp]
+    lib.ntedit_hip_write_outputs_ex.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_char_p), u32,
+                                                ctypes.POINTER(WriteOptions)]
+    lib.ntedit_hip_result_cover_ends.argtypes = [vp, u32, vp]
+    lib.ntedit_hip_result_edits.argtypes = [vp, vp, vp, vp, u32, vp, ctypes.POINTER(vp), ctypes.POINTER(u64),
+                                            ctypes.POINTER(vp)]
     lib.ntedit_hip_filter_occupancy.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.ntedit_hip_set_host_threads.argtypes = [ctypes.c_uint]
     lib.ntedit_hip_set_host_threads.restype = None

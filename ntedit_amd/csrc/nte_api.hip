@@ -99,6 +99,11 @@ struct ntedit_hip_result
 	size_t n_ev_first = 0;
 	ntedit_hip_stats st;
 	nte_host::RenderStats rst;
+	int snv = 0; // -s of the parameters the batch was polished with
+	// ntedit_hip_result_edits(): built on first use
+	bool edits_built = false;
+	std::vector<ntedit_hip_edit> edits;
+	std::string edit_pool;
 };
 
 namespace {
@@ -163,7 +168,7 @@ pin_take(ntedit_hip_ctx* c, size_t bytes, PinBuf* out)
 		c->pin_pool.erase(c->pin_pool.begin() + best);
 		return 0;
 	}
-	// drop the smallest pooled buffer if the pool is getting large
+	// drop the oldest pooled buffer if the pool is getting large
 	if (c->pin_pool.size() >= 4) {
 		(void)hipHostFree(c->pin_pool.front().p);
 		c->pin_pool.erase(c->pin_pool.begin());
@@ -697,7 +702,7 @@ ntedit_hip_set_filter(
     uint32_t k,
     int counting)
 {
-	if (!c || slot < 0 || slot > 1 || !bits || nbytes == 0 || (nbytes & 7)) {
+	if (!c || slot < 0 || slot > 1 || !bits || nbytes == 0) {
 		return fail(c, NTEDIT_E_ARG, "set_filter: bad argument");
 	}
 	HIP_TRY(c, hipSetDevice(c->device));
@@ -706,8 +711,14 @@ ntedit_hip_set_filter(
 		return rc;
 	}
 	DevFilter& f = c->filt[slot];
-	HIP_TRY(c, hipMalloc((void**)&f.data, nbytes));
+	// the slot arithmetic uses exactly nbytes (btllib takes the header's size as it is); only the
+	// allocation is padded to whole 64-bit words (zero-filled: k_popcount reads words)
+	const u64 padded = (nbytes + 7) / 8 * 8;
+	HIP_TRY(c, hipMalloc((void**)&f.data, padded));
 	f.owned = true;
+	if (padded != nbytes) {
+		HIP_TRY(c, hipMemset(f.data + (padded - 8), 0, 8));
+	}
 	HIP_TRY(c, hipMemcpy(f.data, bits, nbytes, hipMemcpyHostToDevice));
 	f.nbytes = nbytes;
 	f.hash_num = hash_num;
@@ -727,8 +738,8 @@ ntedit_hip_set_filter_device(
     uint32_t k,
     int counting)
 {
-	if (!c || slot < 0 || slot > 1 || !device_bits || nbytes == 0 || (nbytes & 7) ||
-	    ((uintptr_t)device_bits & 7)) {
+	// (the caller's allocation must reach the next multiple of 8 bytes, zero-filled behind nbytes)
+	if (!c || slot < 0 || slot > 1 || !device_bits || nbytes == 0 || ((uintptr_t)device_bits & 7)) {
 		return fail(c, NTEDIT_E_ARG, "set_filter_device: bad argument");
 	}
 	HIP_TRY(c, hipSetDevice(c->device));
@@ -754,9 +765,15 @@ ntedit_hip_load_filter_file(ntedit_hip_ctx* c, int slot, const char* path)
 		return fail(c, NTEDIT_E_ARG, "load_filter_file: bad argument");
 	}
 	nte_host::BfHeader h;
-	FILE* f = nte_host::bf_open(path, &h);
+	const char* why = nullptr;
+	FILE* f = nte_host::bf_open(path, &h, &why);
 	if (!f) {
-		return fail(c, NTEDIT_E_IO, "`%s': not a readable btllib Bloom filter file", path);
+		return fail(c, NTEDIT_E_IO, "`%s': %s", path, why ? why : "not a readable btllib Bloom filter file");
+	}
+	if (h.k < 12 || h.k > 200 || h.hash_num > MAX_HASHES) {
+		fclose(f);
+		return fail(c, NTEDIT_E_ARG, "`%s': k = %u, hash_num = %u: this build supports k in [12, 200] and at most %u hash functions",
+		            path, h.k, h.hash_num, MAX_HASHES);
 	}
 	HIP_TRY(c, hipSetDevice(c->device));
 	int rc = drop_filter(c, slot);
@@ -800,7 +817,7 @@ ntedit_hip_load_filter_file(ntedit_hip_ctx* c, int slot, const char* path)
 		drop_filter(c, slot);
 		return fail(c, NTEDIT_E_IO, "`%s': truncated Bloom filter file", path);
 	}
-	d.nbytes = nbytes;
+	d.nbytes = h.bytes; // the size in the header IS the modulus (the allocation is padded to 64-bit words)
 	d.hash_num = h.hash_num;
 	d.k = h.k;
 	d.counting = h.counting;
@@ -927,7 +944,7 @@ ntedit_hip_filter_occupancy(ntedit_hip_ctx* c, int slot, uint64_t* occupied, uin
 	}
 	unsigned long long* d_total = (unsigned long long*)c->counters.p;
 	HIP_TRY(c, hipMemsetAsync(d_total, 0, 8, c->stream));
-	const u64 n_words = f.nbytes / 8; // (filters are whole 64-bit words)
+	const u64 n_words = (f.nbytes + 7) / 8; // (allocations are whole 64-bit words, zero behind nbytes)
 	hipLaunchKernelGGL(k_popcount, dim3((unsigned)(c->cu_count * 8)), dim3(256), 0, c->stream, (const u64*)f.data, n_words,
 	                   f.counting ? 1 : 0, d_total);
 	HIP_TRY(c, hipGetLastError());
@@ -1053,6 +1070,7 @@ ntedit_hip_polish_batch(
 	r->owner = c;
 	memset(&r->st, 0, sizeof r->st);
 	r->st.bases = n;
+	r->snv = c->hp.snv ? 1 : 0;
 	*out = r;
 	if (n == 0 || n_contigs == 0) {
 		return 0;
@@ -1071,6 +1089,14 @@ ntedit_hip_polish_batch(
 		return code;
 	};
 
+	// a HIP error from here on must not leak the result and its pinned buffers (nor leave *out set)
+#define HIP_BAIL(expr)                                                                           \
+	do {                                                                                         \
+		hipError_t e_ = (expr);                                                                  \
+		if (e_ != hipSuccess) {                                                                  \
+			return bail(fail(c, NTEDIT_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)));       \
+		}                                                                                        \
+	} while (0)
 	const u64 n_words = (n + 63) / 64;
 	const u8* d_seq = nullptr;
 	if ((rc = stage_bases(c, bases, n, on_device, &d_seq))) {
@@ -1083,8 +1109,8 @@ ntedit_hip_polish_batch(
 	u64* d_bitmap = (u64*)c->bitmap.p;
 	hipStream_t sA = c->stream;  // screening
 	hipStream_t sB = c->stream2; // event extraction + event machine
-	HIP_TRY(c, hipMemcpyAsync(c->offs.p, offsets, (size_t)n_contigs * 8, hipMemcpyHostToDevice, sA));
-	HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n_contigs * 4, hipMemcpyHostToDevice, sA));
+	HIP_BAIL(hipMemcpyAsync(c->offs.p, offsets, (size_t)n_contigs * 8, hipMemcpyHostToDevice, sA));
+	HIP_BAIL(hipMemcpyAsync(c->lens.p, lens, (size_t)n_contigs * 4, hipMemcpyHostToDevice, sA));
 
 	// ---- chunk plan: whole contigs, cut at SCREEN_TILE boundaries of the screening pass.
 	// Chunk j's screening covers tiles [t0, t1) with t1 = ceil(end of its last contig / TILE),
@@ -1139,7 +1165,7 @@ ntedit_hip_polish_batch(
 	const bool pipelined = n_ch > 1;
 	while (c->chunk_ev.size() < 2 * n_ch) {
 		hipEvent_t e;
-		HIP_TRY(c, hipEventCreate(&e));
+		HIP_BAIL(hipEventCreate(&e));
 		c->chunk_ev.push_back(e);
 	}
 
@@ -1171,32 +1197,32 @@ ntedit_hip_polish_batch(
 		}
 		// counters layout (bytes): [0] absent k-mers u64, [8] starts of the current chunk u64,
 		// [32] arena cursor u32, [40] status u32, [44] deferred count u32
-		HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 256, sA));
-		HIP_TRY(c, hipStreamSynchronize(sA));
+		HIP_BAIL(hipMemsetAsync(c->counters.p, 0, 256, sA));
+		HIP_BAIL(hipStreamSynchronize(sA));
 		unsigned long long* d_counters = (unsigned long long*)c->counters.p;
 		u32* d_arena_next = (u32*)((char*)c->counters.p + 32);
 		u32* d_status = (u32*)((char*)c->counters.p + 40);
 		u32* d_ndef = (u32*)((char*)c->counters.p + 44);
 
 		// ---- stream A: every chunk's screening, back to back
-		HIP_TRY(c, hipEventRecord(c->ev[0], sA));
+		HIP_BAIL(hipEventRecord(c->ev[0], sA));
 		if (!pipelined) {
-			HIP_TRY(c, hipEventRecord(c->chunk_ev[0], sA));
+			HIP_BAIL(hipEventRecord(c->chunk_ev[0], sA));
 			if ((rc = launch_screen<false>(c, d_seq, n, f0, d_bitmap, n_words))) {
 				return bail(rc);
 			}
-			HIP_TRY(c, hipEventRecord(c->chunk_ev[1], sA));
+			HIP_BAIL(hipEventRecord(c->chunk_ev[1], sA));
 		} else {
 			for (size_t j = 0; j < n_ch; j++) {
-				HIP_TRY(c, hipEventRecord(c->chunk_ev[2 * j], sA));
+				HIP_BAIL(hipEventRecord(c->chunk_ev[2 * j], sA));
 				if ((rc = launch_screen_tiles<false>(
 				         c, sA, d_seq, n, f0, d_bitmap, n_words, chunks[j].t0, chunks[j].t1 - chunks[j].t0, screen_pad))) {
 					return bail(rc);
 				}
-				HIP_TRY(c, hipEventRecord(c->chunk_ev[2 * j + 1], sA));
+				HIP_BAIL(hipEventRecord(c->chunk_ev[2 * j + 1], sA));
 			}
 		}
-		HIP_TRY(c, hipEventRecord(c->ev[1], sA));
+		HIP_BAIL(hipEventRecord(c->ev[1], sA));
 
 		// ---- stream B: per chunk, as soon as its screening is done
 		u64 ev_total = 0;      // events of the chunks processed so far
@@ -1233,9 +1259,9 @@ ntedit_hip_polish_batch(
 		};
 		for (size_t j = 0; j < n_ch && status == 0; j++) {
 			const Chunk& ch = chunks[j];
-			HIP_TRY(c, hipStreamWaitEvent(sB, c->chunk_ev[2 * j + 1], 0));
+			HIP_BAIL(hipStreamWaitEvent(sB, c->chunk_ev[2 * j + 1], 0));
 			if (first_b) {
-				HIP_TRY(c, hipEventRecord(c->ev[2], sB));
+				HIP_BAIL(hipEventRecord(c->ev[2], sB));
 				first_b = false;
 			}
 			const u64 w0 = ch.b0 / 64, w1 = (ch.b1 + 63) / 64;
@@ -1246,7 +1272,7 @@ ntedit_hip_polish_batch(
 			if ((rc = ensure(c, c->block_counts, n_sblocks * 4)) || (rc = ensure(c, c->block_offsets, n_sblocks * 8))) {
 				return bail(rc);
 			}
-			HIP_TRY(c, hipMemsetAsync((char*)c->counters.p + 8, 0, 8, sB));
+			HIP_BAIL(hipMemsetAsync((char*)c->counters.p + 8, 0, 8, sB));
 			hipLaunchKernelGGL(
 			    k_count_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_bitmap, w0, w1, ch.b0, ch.b1, grid_lo,
 			    grid, (u32*)c->block_counts.p, d_counters);
@@ -1254,8 +1280,8 @@ ntedit_hip_polish_batch(
 			    k_scan_counts, dim3(1), dim3(1024), 0, sB, (const u32*)c->block_counts.p, n_sblocks,
 			    (unsigned long long*)c->block_offsets.p, d_counters);
 			unsigned long long h_counters[2] = { 0, 0 };
-			HIP_TRY(c, hipMemcpyAsync(h_counters, d_counters, 16, hipMemcpyDeviceToHost, sB));
-			HIP_TRY(c, hipStreamSynchronize(sB));
+			HIP_BAIL(hipMemcpyAsync(h_counters, d_counters, 16, hipMemcpyDeviceToHost, sB));
+			HIP_BAIL(hipStreamSynchronize(sB));
 			const u64 n_ev = h_counters[1];
 			absent_total = h_counters[0];
 			if (n_ev == 0) {
@@ -1273,9 +1299,9 @@ ntedit_hip_polish_batch(
 					return bail(rc);
 				}
 				if (ev_total) {
-					HIP_TRY(c, hipMemcpyAsync(ne.p, c->events.p, ev_total * 8, hipMemcpyDeviceToDevice, sB));
-					HIP_TRY(c, hipMemcpyAsync(nf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToDevice, sB));
-					HIP_TRY(c, hipStreamSynchronize(sB));
+					HIP_BAIL(hipMemcpyAsync(ne.p, c->events.p, ev_total * 8, hipMemcpyDeviceToDevice, sB));
+					HIP_BAIL(hipMemcpyAsync(nf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToDevice, sB));
+					HIP_BAIL(hipStreamSynchronize(sB));
 				}
 				release(c->events);
 				release(c->first_chunk);
@@ -1345,17 +1371,17 @@ ntedit_hip_polish_batch(
 			if (n_ch != 1) {
 				a.p.event_budget = 0; // (parked events are re-run per batch: single-chunk batches only)
 			}
-			HIP_TRY(c, hipMemsetAsync(d_ndef, 0, 4, sB));
-			HIP_TRY(c, hipEventRecord(c->ev[3], sB));
+			HIP_BAIL(hipMemsetAsync(d_ndef, 0, 4, sB));
+			HIP_BAIL(hipEventRecord(c->ev[3], sB));
 			// pass 1: every event, indel sweeps postponed
-			HIP_TRY(c, hipMemsetAsync(a.work_counter, 0, 4, sB));
+			HIP_BAIL(hipMemsetAsync(a.work_counter, 0, 4, sB));
 			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] pass1 launch: blocks %llu events %llu\n", (unsigned long long)blocks, (unsigned long long)a.n_events); }
 			launch_k_machine_thread((unsigned)blocks, dyn_lds, sB, a);
-			HIP_TRY(c, hipGetLastError());
+			HIP_BAIL(hipGetLastError());
 			u32 h_tail[4] = { 0, 0, 0, 0 };
-			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
-			HIP_TRY(c, hipEventRecord(c->ev[5], sB));
-			HIP_TRY(c, hipStreamSynchronize(sB));
+			HIP_BAIL(hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+			HIP_BAIL(hipEventRecord(c->ev[5], sB));
+			HIP_BAIL(hipStreamSynchronize(sB));
 			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] pass1 done: deferred %u status %u\n", h_tail[3], h_tail[2]); }
 			const u32 n_def = h_tail[3];
 			deferred_total += n_def;
@@ -1369,7 +1395,7 @@ ntedit_hip_polish_batch(
 					return bail(rc);
 				}
 				if (early_chunks) {
-					HIP_TRY(c, hipMemcpyAsync(early.p, c->arena.p, early_chunks * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sA));
+					HIP_BAIL(hipMemcpyAsync(early.p, c->arena.p, early_chunks * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sA));
 				}
 			}
 			if (n_def > 0 && status == 0) {
@@ -1379,12 +1405,12 @@ ntedit_hip_polish_batch(
 					a2.p.debug_stop = (u32)atoi(dbg); // timing ablations; results are NOT valid
 				}
 				launch_wave_pass(a2, (const u32*)c->deferred.p, n_def);
-				HIP_TRY(c, hipGetLastError());
+				HIP_BAIL(hipGetLastError());
 			}
 			keep_a = a;
-			HIP_TRY(c, hipEventRecord(c->ev[4], sB));
-			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
-			HIP_TRY(c, hipStreamSynchronize(sB));
+			HIP_BAIL(hipEventRecord(c->ev[4], sB));
+			HIP_BAIL(hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+			HIP_BAIL(hipStreamSynchronize(sB));
 			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] pass2 done: status %u\n", h_tail[2]); }
 			status = h_tail[2];
 			float p1 = 0.f, p2 = 0.f;
@@ -1409,11 +1435,11 @@ ntedit_hip_polish_batch(
 			}
 			ev_total += n_ev;
 		}
-		HIP_TRY(c, hipStreamSynchronize(sA));
-		HIP_TRY(c, hipStreamSynchronize(sB));
+		HIP_BAIL(hipStreamSynchronize(sA));
+		HIP_BAIL(hipStreamSynchronize(sB));
 		if (status == 0) {
 			u32 h_tail[4] = { 0, 0, 0, 0 };
-			HIP_TRY(c, hipMemcpy(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost));
+			HIP_BAIL(hipMemcpy(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost));
 			const u64 used_chunks = h_tail[0] < arena_chunks ? h_tail[0] : arena_chunks;
 			r->st.absent_kmers = absent_total;
 			r->st.events = ev_total;
@@ -1436,17 +1462,17 @@ ntedit_hip_polish_batch(
 			}
 			if (used_chunks > have) {
 				const size_t off = (size_t)have * CHUNK_ITEMS * sizeof(Item);
-				HIP_TRY(c, hipMemcpyAsync((char*)r->arena_buf.p + off, (char*)c->arena.p + off, r->arena_items * sizeof(Item) - off, hipMemcpyDeviceToHost, sB));
+				HIP_BAIL(hipMemcpyAsync((char*)r->arena_buf.p + off, (char*)c->arena.p + off, r->arena_items * sizeof(Item) - off, hipMemcpyDeviceToHost, sB));
 			}
 			if (ev_total) {
-				HIP_TRY(c, hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));
+				HIP_BAIL(hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));
 			}
-			HIP_TRY(c, hipStreamSynchronize(sB));
+			HIP_BAIL(hipStreamSynchronize(sB));
 			// Events parked by the budget: decide, in serial order, which of them are applied, re-run
 			// exactly those to completion, carry on behind them (host/resolve.h).  Nothing to do in
 			// the ordinary case.
 			u32 n_unfinished = 0;
-			HIP_TRY(c, hipMemcpy(&n_unfinished, (char*)c->counters.p + 52, 4, hipMemcpyDeviceToHost));
+			HIP_BAIL(hipMemcpy(&n_unfinished, (char*)c->counters.p + 52, 4, hipMemcpyDeviceToHost));
 			bool redo = false;
 			if (n_unfinished && n_ch == 1) {
 				nte_host::Resolver rs((const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p, ev_total);
@@ -1457,14 +1483,14 @@ ntedit_hip_polish_batch(
 				u64 have_chunks = used_chunks;
 				unsigned rounds = 0;
 				while (!rerun.empty()) {
-					HIP_TRY(c, hipMemcpyAsync(c->deferred.p, rerun.data(), rerun.size() * 4, hipMemcpyHostToDevice, sB));
+					HIP_BAIL(hipMemcpyAsync(c->deferred.p, rerun.data(), rerun.size() * 4, hipMemcpyHostToDevice, sB));
 					MachineArgs ra = keep_a;
 					ra.p.event_budget = 0;
 					launch_wave_pass(ra, (const u32*)c->deferred.p, (u32)rerun.size());
-					HIP_TRY(c, hipGetLastError());
+					HIP_BAIL(hipGetLastError());
 					u32 t2[4] = { 0, 0, 0, 0 };
-					HIP_TRY(c, hipMemcpyAsync(t2, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
-					HIP_TRY(c, hipStreamSynchronize(sB));
+					HIP_BAIL(hipMemcpyAsync(t2, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+					HIP_BAIL(hipStreamSynchronize(sB));
 					if (t2[2]) {
 						status = t2[2];
 						redo = true;
@@ -1483,11 +1509,11 @@ ntedit_hip_polish_batch(
 					}
 					if (now_chunks > have_chunks) {
 						const size_t off = (size_t)have_chunks * CHUNK_ITEMS * sizeof(Item);
-						HIP_TRY(c, hipMemcpyAsync((char*)r->arena_buf.p + off, (char*)c->arena.p + off,
+						HIP_BAIL(hipMemcpyAsync((char*)r->arena_buf.p + off, (char*)c->arena.p + off,
 						                          (size_t)(now_chunks - have_chunks) * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sB));
 					}
-					HIP_TRY(c, hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));
-					HIP_TRY(c, hipStreamSynchronize(sB));
+					HIP_BAIL(hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));
+					HIP_BAIL(hipStreamSynchronize(sB));
 					have_chunks = now_chunks;
 					r->arena_items = (size_t)now_chunks * CHUNK_ITEMS;
 					rs.rebind((const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p);
@@ -1505,8 +1531,8 @@ ntedit_hip_polish_batch(
 				pin_give(c, r->arena_buf);
 				pin_give(c, r->first_buf);
 			} else {
-			HIP_TRY(c, hipEventRecord(c->ev[4], sB));
-			HIP_TRY(c, hipStreamSynchronize(sB));
+			HIP_BAIL(hipEventRecord(c->ev[4], sB));
+			HIP_BAIL(hipStreamSynchronize(sB));
 			// one entry per event, in position order; NONE32 = the event produced nothing (the
 			// renderer skips those)
 			r->n_ev_first = ev_total;
@@ -1523,7 +1549,7 @@ ntedit_hip_polish_batch(
 			r->st.ms_machine = ms_machine;
 			(void)ms_extract;
 			r->st.ms_extract = 0.f;
-			HIP_TRY(c, hipEventElapsedTime(&r->st.ms_total, c->ev[0], c->ev[4]));
+			HIP_BAIL(hipEventElapsedTime(&r->st.ms_total, c->ev[0], c->ev[4]));
 			c->last_ms = ms_screen;
 			break;
 			}
@@ -1539,6 +1565,7 @@ ntedit_hip_polish_batch(
 		}
 	}
 	return 0;
+#undef HIP_BAIL
 }
 
 void
@@ -1608,23 +1635,22 @@ ntedit_hip_write_vcf_header(const char* vcf_path, const char* draft_filename)
 }
 
 int
-ntedit_hip_write_outputs_vcf(
+ntedit_hip_write_outputs_ex(
     const ntedit_hip_result* r,
     const char* bases,
     const uint64_t* offsets,
     const uint32_t* lens,
     const char* const* names,
     uint32_t n_contigs,
-    const char* fa_path,
-    const char* tsv_path,
-    const char* vcf_path,
-    int append,
-    int snv,
-    const ntedit_hip_annot* annot)
+    const ntedit_hip_write_options* wo)
 {
-	if (!r || (n_contigs && (!bases || !offsets || !lens || !names))) {
+	if (!r || !wo || (n_contigs && (!bases || !offsets || !lens || !names))) {
 		return NTEDIT_E_ARG;
 	}
+	const char* fa_path = wo->fa_path;
+	const char* tsv_path = wo->tsv_path;
+	const char* vcf_path = wo->vcf_path;
+	const int append = wo->append;
 	FILE* fa = fa_path ? fopen(fa_path, append ? "ab" : "wb") : nullptr;
 	FILE* tsv = tsv_path ? fopen(tsv_path, append ? "ab" : "wb") : nullptr;
 	FILE* vcf = vcf_path ? fopen(vcf_path, append ? "ab" : "wb") : nullptr;
@@ -1653,8 +1679,13 @@ ntedit_hip_write_outputs_vcf(
 	rw->rst = nte_host::RenderStats();
 	nte_host::RenderOptions opt;
 	opt.threads = g_host_threads.load();
-	opt.snv = snv != 0;
-	opt.annot = annot ? annot->a : nullptr;
+	opt.snv = r->snv != 0;
+	opt.annot = wo->annot ? wo->annot->a : nullptr;
+	opt.segments = wo->segments;
+	opt.out_sizes = wo->out_sizes;
+	if (wo->out_sizes) {
+		memset(wo->out_sizes, 0, (size_t)n_contigs * 3 * sizeof(uint64_t));
+	}
 	int rc = nte_host::render_batch(
 	    (const Item*)r->arena_buf.p,
 	    r->arena_items,
@@ -1671,15 +1702,100 @@ ntedit_hip_write_outputs_vcf(
 	    vcf,
 	    &opt);
 	if (fa && fclose(fa) != 0) {
-		rc = rc ? rc : NTEDIT_E_IO;
+		rc = rc ? rc : -5;
 	}
 	if (tsv && fclose(tsv) != 0) {
-		rc = rc ? rc : NTEDIT_E_IO;
+		rc = rc ? rc : -5;
 	}
 	if (vcf && fclose(vcf) != 0) {
-		rc = rc ? rc : NTEDIT_E_IO;
+		rc = rc ? rc : -5;
+	}
+	if (rc == -7 || rc == -8) {
+		return NTEDIT_E_SEGMENT;
 	}
 	return rc ? NTEDIT_E_IO : 0;
+}
+
+int
+ntedit_hip_write_outputs_vcf(
+    const ntedit_hip_result* r,
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    const char* const* names,
+    uint32_t n_contigs,
+    const char* fa_path,
+    const char* tsv_path,
+    const char* vcf_path,
+    int append,
+    int snv,
+    const ntedit_hip_annot* annot)
+{
+	(void)snv; // (SNV mode follows the parameters the batch was polished with)
+	ntedit_hip_write_options wo;
+	memset(&wo, 0, sizeof wo);
+	wo.fa_path = fa_path;
+	wo.tsv_path = tsv_path;
+	wo.vcf_path = vcf_path;
+	wo.append = append;
+	wo.annot = annot;
+	return ntedit_hip_write_outputs_ex(r, bases, offsets, lens, names, n_contigs, &wo);
+}
+
+int
+ntedit_hip_result_cover_ends(const ntedit_hip_result* r, uint32_t n_contigs, uint32_t* cover_ends)
+{
+	if (!r || (n_contigs && !cover_ends)) {
+		return NTEDIT_E_ARG;
+	}
+	return nte_host::cover_ends((const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p, r->n_ev_first,
+	                            n_contigs, cover_ends)
+	           ? NTEDIT_E_ARG
+	           : 0;
+}
+
+int
+ntedit_hip_result_edits(
+    ntedit_hip_result* r,
+    const char* bases,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    uint32_t n_contigs,
+    const ntedit_hip_segment* segments,
+    const ntedit_hip_edit** edits,
+    uint64_t* n_edits,
+    const char** base_pool)
+{
+	if (!r || !edits || !n_edits || (n_contigs && (!bases || !offsets || !lens))) {
+		return NTEDIT_E_ARG;
+	}
+	if (!r->edits_built) {
+		r->edits.clear();
+		r->edit_pool.clear();
+		std::vector<const char*> names(n_contigs, "");
+		nte_host::RenderOptions opt;
+		opt.threads = g_host_threads.load();
+		opt.snv = r->snv != 0;
+		opt.segments = segments;
+		opt.edits = &r->edits;
+		opt.edit_pool = &r->edit_pool;
+		nte_host::RenderStats st;
+		const int rc = nte_host::render_batch(
+		    (const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p, r->n_ev_first, bases, offsets, lens,
+		    names.data(), n_contigs, nullptr, nullptr, &st, nullptr, &opt);
+		if (rc) {
+			r->edits.clear();
+			r->edit_pool.clear();
+			return rc == -7 || rc == -8 ? NTEDIT_E_SEGMENT : NTEDIT_E_ARG;
+		}
+		r->edits_built = true;
+	}
+	*edits = r->edits.data();
+	*n_edits = r->edits.size();
+	if (base_pool) {
+		*base_pool = r->edit_pool.c_str();
+	}
+	return 0;
 }
 
 int

@@ -6,12 +6,18 @@
 namespace nte_host {
 
 FILE*
-bf_open(const char* path, BfHeader* h)
+bf_open(const char* path, BfHeader* h, const char** why)
 {
+	const char* dummy;
+	if (!why) {
+		why = &dummy;
+	}
+	*why = "cannot open the file";
 	FILE* f = fopen(path, "rb");
 	if (!f) {
 		return nullptr;
 	}
+	*why = "not a btllib Bloom filter file (no [BTL...BloomFilter...] signature line)";
 	char line[1024];
 	bool first = true, ended = false;
 	*h = BfHeader();
@@ -48,12 +54,40 @@ bf_open(const char* path, BfHeader* h)
 			h->hash_num = (uint32_t)strtoul(val, nullptr, 10);
 		} else if (!strcmp(key, "k")) {
 			h->k = (uint32_t)strtoul(val, nullptr, 10);
+		} else if (!strcmp(key, "hash_fn")) {
+			const char* q = strchr(val, '"');
+			size_t n = 0;
+			if (q) {
+				for (q++; *q && *q != '"' && n + 1 < sizeof h->hash_fn; q++) {
+					h->hash_fn[n++] = *q;
+				}
+			}
+			h->hash_fn[n] = 0;
 		}
 	}
-	if (!ended || h->bytes == 0 || h->hash_num == 0) {
+	const char* bad = nullptr;
+	if (first) {
+		bad = "empty file";
+	} else if (!ended) {
+		bad = *why; // (signature missing) or:
+		if (h->bytes || h->hash_num || h->k) {
+			bad = "header without [HeaderEnd]";
+		}
+	} else if (h->bytes == 0) {
+		bad = "header has no `bytes`";
+	} else if (h->hash_num == 0) {
+		bad = "header has no `hash_num`";
+	} else if (h->k == 0) {
+		bad = "header has no `k` (a plain btllib BloomFilter, not a k-mer Bloom filter)";
+	} else if (h->hash_fn[0] && strcmp(h->hash_fn, "ntHash_v2") != 0) {
+		bad = "hash_fn is not \"ntHash_v2\" (filter written with another hash function)";
+	}
+	if (bad) {
+		*why = bad;
 		fclose(f);
 		return nullptr;
 	}
+	*why = nullptr;
 	return f;
 }
 

@@ -23,11 +23,13 @@ struct BfHeader
 	uint32_t hash_num = 0;
 	uint32_t k = 0;
 	bool counting = false;
+	char hash_fn[32] = { 0 }; // as written in the header ("ntHash_v2" for every filter ntEdit can use)
 };
 
 // opens the file and parses the header; on success the returned FILE* is
-// positioned at the first byte of the array.  nullptr on any error.
-FILE* bf_open(const char* path, BfHeader* h);
+// positioned at the first byte of the array.  nullptr on any error; why (when not nullptr) then says
+// what was wrong with the file.
+FILE* bf_open(const char* path, BfHeader* h, const char** why = nullptr);
 // writes header + array; 0 on success
 int bf_save(const char* path, const BfHeader& h, const uint8_t* data);
 

@@ -70,11 +70,27 @@ FastaReader::io_loop_()
 			s = (int)(head_ % NSLOTS);
 		}
 		int n = gzread(f_, slot_[s], BUFSZ);
+		bool bad = n < 0;
+		std::string why;
+		if (n < BUFSZ) {
+			// a short or failed read: end of file, or a stream that broke (zlib reports a truncated
+			// .gz as Z_BUF_ERROR and corrupt data as Z_DATA_ERROR only through gzerror)
+			int errnum = Z_OK;
+			const char* msg = gzerror(f_, &errnum);
+			if (errnum != Z_OK && errnum != Z_STREAM_END) {
+				bad = true;
+				why = msg ? msg : "read error";
+			}
+		}
 		if (n < 0) {
 			n = 0;
 		}
 		{
 			std::lock_guard<std::mutex> lk(mu_);
+			if (bad) {
+				io_error_ = true;
+				io_error_text_ = why.empty() ? "read error" : why;
+			}
 			slot_len_[s] = n;
 			head_++;
 		}

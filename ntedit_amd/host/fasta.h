@@ -19,6 +19,11 @@ class FastaReader
 	explicit FastaReader(const char* path);
 	~FastaReader();
 	bool ok() const { return f_ != nullptr; }
+	// set once the input turned out to be unreadable half-way (corrupt or truncated .gz, I/O error): next()
+	// then returns false as at the end of the file, and the caller must not treat what it got as the whole draft
+	// (kseq, lib/kseq.h:103-107, treats a failed read as the end of the input; a polished genome that is silently shorter is worse)
+	bool io_error() const { return io_error_; }
+	const std::string& io_error_text() const { return io_error_text_; }
 	// reads the next record; header = name [+ " " + comment]; the sequence is APPENDED to seq
 	// (so a batch can be assembled without an intermediate copy); false at EOF
 	bool next(std::string& header, std::string& seq);
@@ -43,6 +48,8 @@ class FastaReader
 	unsigned long long head_, tail_; // blocks produced / consumed
 	int cur_;
 	bool stop_;
+	bool io_error_ = false; // written by the I/O thread before it publishes the final (empty) block
+	std::string io_error_text_;
 	std::mutex mu_;
 	std::condition_variable cv_;
 	std::thread io_;

@@ -2,8 +2,9 @@
 //
 // Keeps the reference's command-line surface (ntedit.cpp:135-169, 2276-2364):
 //   -t -f -r -e -b -z -i -d -x -y -X -Y -c -j -m -s -l -a -v -p -q -k --help --version
-// (-k is accepted and ignored, exactly like the reference: k comes from the
-// Bloom filter header; -c is parsed and overwritten by k*1.5; -t sets the host
+// (-k is accepted and ignored: k comes from the Bloom filter header.  The reference lists -k in its
+// option string but has no `case 'k'`, so `-k N` trips its "invalid option" check, ntedit.cpp:2360-2363;
+// being lenient here keeps old command lines working.  -c is parsed and overwritten by k*1.5; -t sets the host
 // threads that render the output, contigs themselves are polished on the GPU and
 // the output order is the input order, i.e. the reference at -t 1).  Reads the draft with kseq semantics, batches
 // contigs, calls the C ABI (include/ntedit_hip.h) and writes
@@ -268,7 +269,7 @@ main(int argc, char** argv)
 			parse(c, optarg, p.max_threshold);
 			break;
 		case 'k':
-			break; // accepted and ignored, like the reference (no `case 'k'` there)
+			break; // accepted and ignored (the reference rejects it: no `case 'k'`, ntedit.cpp:2360-2363)
 		case OPT_GPU:
 			parse(c, optarg, gpu);
 			break;
@@ -577,6 +578,12 @@ main(int argc, char** argv)
 	write_q.push(nullptr);
 	reader_thread.join();
 	writer_thread.join();
+	if (reader.io_error()) {
+		// a corrupt / truncated input must not pass for a (shorter) genome
+		fprintf(stderr, PROGRAM ": error: `%s': %s -- the outputs are incomplete\n", draft.c_str(), reader.io_error_text().c_str());
+		fflush(nullptr);
+		_exit(EXIT_FAILURE);
+	}
 	auto t1 = std::chrono::steady_clock::now();
 	time(&rawtime);
 	printf("---------- process complete                         : %s", ctime(&rawtime));

@@ -175,6 +175,10 @@ struct ContigOut
 	RenderStats st;
 	int rc = 0;
 	bool ready = false;
+	size_t fa_bytes = 0;              // bytes of the unit's FASTA pieces so far
+	std::vector<uint64_t> sizes;      // 3 per contig of the unit: fa / tsv / vcf bytes (RenderOptions::out_sizes)
+	std::vector<ntedit_hip_edit> edits; // RenderOptions::edits
+	std::string edit_pool;
 
 	void reset()
 	{
@@ -185,6 +189,10 @@ struct ContigOut
 		seq_keep.clear();
 		st = RenderStats();
 		rc = 0;
+		fa_bytes = 0;
+		sizes.clear();
+		edits.clear();
+		edit_pool.clear();
 	}
 	void begin_contig()
 	{
@@ -202,23 +210,25 @@ struct ContigOut
 			fa.push_back(pc);
 		}
 		text.append(s, n);
+		fa_bytes += n;
 	}
 	void fa_char(char c) { fa_text(&c, 1); }
 	void fa_span(const char* s, size_t n)
 	{
 		Piece pc = { s, 0, n };
 		fa.push_back(pc);
+		fa_bytes += n;
 	}
 };
 
 // the substitution line of _variants.vcf (ntedit.cpp:986-1162)
 void
-write_vcf_substitution(std::string& vcf, const std::string& H, const RSub& s, const RenderOptions& opt, bool is_edit)
+write_vcf_substitution(std::string& vcf, const std::string& H, const RSub& s, const RenderOptions& opt, bool is_edit, uint64_t off)
 {
 	std::string base(1, (char)s.sub);
 	std::string support = std::to_string(s.support);
 	const char D = (char)toupper(s.draft);
-	const std::string pos1 = std::to_string(s.pos + 1);
+	const std::string pos1 = std::to_string((uint64_t)s.pos + 1 + off);
 	std::vector<std::string> ids;
 	ids.push_back(H + ">" + D + pos1 + D);
 	if (is_edit) {
@@ -299,7 +309,7 @@ write_vcf_substitution(std::string& vcf, const std::string& H, const RSub& s, co
 	// "%s\t%u\t.\t%c\t%s\t.\tPASS\tAD=%s"
 	vcf += H;
 	vcf.push_back('\t');
-	put_u(vcf, (uint64_t)s.pos + 1);
+	put_u(vcf, (uint64_t)s.pos + 1 + off);
 	vcf += "\t.\t";
 	vcf.push_back((char)s.draft);
 	vcf.push_back('\t');
@@ -315,8 +325,13 @@ write_vcf_substitution(std::string& vcf, const std::string& H, const RSub& s, co
 }
 
 // Renders one record the way writeEditsToFile walks the rope (ntedit.cpp:936-1212).
+// sg (may be nullptr): the record is one segment of a contig that was cut for multi-GPU sharding -- its
+// positions are shifted by sg->pos_offset, a segment that is not the first has no header line, one that is
+// not the last no closing newline (the caller has already taken the look-ahead halo off the last node).
+// want_edits: every TSV row is also handed on as an ntedit_hip_edit record (entry index ci).
 void
-write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool want_tsv, bool want_vcf, const RenderOptions& opt)
+write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool want_tsv, bool want_vcf, const RenderOptions& opt,
+             const ntedit_hip_segment* sg, uint32_t ci, bool want_edits)
 {
 	const std::vector<RNode>& nodes = o.nodes;
 	const std::vector<RSub>& subs = o.subs;
@@ -324,7 +339,40 @@ write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool 
 	std::string& tsv = o.tsv;
 	std::string& vcf = o.vcf;
 	const std::string H(hdr);
-	if (want_fa) {
+	const uint64_t off = sg ? sg->pos_offset : 0;
+	const uint32_t sflags = sg ? sg->flags : 0;
+	auto add_edit = [&](uint8_t kind, uint32_t dpos, const char* bases, size_t nb, uint32_t support, uint8_t draft, uint8_t nbase,
+	                    const RSub* alt) {
+		ntedit_hip_edit e;
+		memset(&e, 0, sizeof e);
+		e.contig = ci;
+		e.draft_pos = (uint32_t)(dpos + off);
+		e.bases_off = (uint32_t)o.edit_pool.size();
+		e.len = (uint16_t)(nb > 0xFFFF ? 0xFFFF : nb);
+		e.support = (uint16_t)(support > 0xFFFF ? 0xFFFF : support);
+		e.kind = kind;
+		e.draft_base = draft;
+		e.new_base = nbase;
+		if (alt) {
+			if (alt->s1 > 0) {
+				e.alt_base[e.n_alt] = alt->a1;
+				e.alt_support[e.n_alt++] = (uint8_t)alt->s1;
+			}
+			if (alt->s2 > 0) {
+				e.alt_base[e.n_alt] = alt->a2;
+				e.alt_support[e.n_alt++] = (uint8_t)alt->s2;
+			}
+			if (alt->s3 > 0) {
+				e.alt_base[e.n_alt] = alt->a3;
+				e.alt_support[e.n_alt++] = (uint8_t)alt->s3;
+			}
+		}
+		if (bases && nb) {
+			o.edit_pool.append(bases, nb);
+		}
+		o.edits.push_back(e);
+	};
+	if (want_fa && !(sflags & NTEDIT_SEG_NO_HEADER)) {
 		o.fa_char('>');
 		o.fa_text(H.data(), H.size());
 		o.fa_char('\n');
@@ -346,7 +394,7 @@ write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool 
 					// "%s\t%u\t%c\t+%s\t%d\n" (%s stops at an embedded NUL, like the reference's c_str())
 					tsv += H;
 					tsv.push_back('\t');
-					put_u(tsv, pos);
+					put_u(tsv, pos + off);
 					tsv.push_back('\t');
 					tsv.push_back((char)draft_char);
 					tsv += "\t+";
@@ -360,7 +408,7 @@ write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool 
 					const char D = (char)toupper(draft_char);
 					vcf += H;
 					vcf.push_back('\t');
-					put_u(vcf, pos);
+					put_u(vcf, pos + off);
 					vcf += "\t.\t";
 					vcf.push_back((char)draft_char);
 					vcf.push_back('\t');
@@ -368,8 +416,11 @@ write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool 
 					vcf += ins.c_str();
 					vcf += "\t.\tPASS\tAD=";
 					put_i(vcf, num_support);
-					put_annot(vcf, opt.annot, H + ">" + D + std::to_string(pos) + D + upper(ins.data(), ins.size()));
+					put_annot(vcf, opt.annot, H + ">" + D + std::to_string(pos + off) + D + upper(ins.data(), ins.size()));
 					vcf += "\tGT\t1/1\n";
+				}
+				if (want_edits) {
+					add_edit(NTEDIT_EDIT_INS, pos, ins.data(), ins.size(), (uint32_t)(num_support < 0 ? 0 : num_support), draft_char, 0, nullptr);
 				}
 				st->insertions++;
 				ins.clear();
@@ -379,12 +430,15 @@ write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool 
 				const RSub& s = subs[qi];
 				const bool is_edit = !(opt.snv && s.draft == s.sub); // "snv_mode_no_edit" in the reference
 				if (want_vcf) {
-					write_vcf_substitution(vcf, H, s, opt, is_edit);
+					write_vcf_substitution(vcf, H, s, opt, is_edit, off);
+				}
+				if (want_edits) {
+					add_edit(is_edit ? NTEDIT_EDIT_SUB : NTEDIT_EDIT_SNV_KEPT, s.pos, nullptr, 1, s.support, s.draft, s.sub, &s);
 				}
 				if (want_tsv && is_edit) {
 					tsv += H;
 					tsv.push_back('\t');
-					put_u(tsv, (uint64_t)s.pos + 1);
+					put_u(tsv, (uint64_t)s.pos + 1 + off);
 					tsv.push_back('\t');
 					tsv.push_back((char)s.draft);
 					tsv.push_back('\t');
@@ -437,7 +491,7 @@ write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool 
 					// "%s\t%u\t%c\t-" + the deleted bases + "\t%u\n"
 					tsv += H;
 					tsv.push_back('\t');
-					put_u(tsv, pos);
+					put_u(tsv, pos + off);
 					tsv.push_back('\t');
 					tsv.push_back(seq[pos]);
 					tsv += "\t-";
@@ -451,7 +505,7 @@ write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool 
 					const size_t dl = (size_t)(nx.s_pos - pos) + 1;
 					vcf += H;
 					vcf.push_back('\t');
-					put_u(vcf, pos);
+					put_u(vcf, pos + off);
 					vcf += "\t.\t";
 					vcf.append(seq + pos - 1, dl);
 					vcf.push_back('\t');
@@ -459,14 +513,17 @@ write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool 
 					vcf += "\t.\tPASS\tAD=";
 					put_u(vcf, nx.support);
 					put_annot(vcf, opt.annot,
-					          H + ">" + upper(seq + pos - 1, dl) + std::to_string(pos) + (char)toupper((unsigned char)seq[pos - 1]));
+					          H + ">" + upper(seq + pos - 1, dl) + std::to_string(pos + off) + (char)toupper((unsigned char)seq[pos - 1]));
 					vcf += "\tGT\t1/1\n";
+				}
+				if (want_edits) {
+					add_edit(NTEDIT_EDIT_DEL, pos, seq + pos, (size_t)nx.s_pos - pos, nx.support, (uint8_t)seq[pos], 0, nullptr);
 				}
 				st->deletions++;
 			}
 		}
 	}
-	if (want_fa) {
+	if (want_fa && !(sflags & NTEDIT_SEG_NO_NEWLINE)) {
 		o.fa_char('\n');
 	}
 }
@@ -480,7 +537,7 @@ struct BatchView
 	const uint64_t* offsets;
 	const uint32_t* lens;
 	const char* const* names;
-	bool want_fa, want_tsv, want_vcf;
+	bool want_fa, want_tsv, want_vcf, want_edits;
 	RenderOptions opt;
 };
 
@@ -493,6 +550,14 @@ render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigO
 	const uint32_t len = v.lens[ci];
 	const Item* arena = v.arena;
 	const size_t arena_items = v.arena_items;
+	const ntedit_hip_segment* sg = v.opt.segments ? &v.opt.segments[ci] : nullptr;
+	const uint32_t halo = sg ? sg->halo : 0;
+	if (sg && ((sg->flags & NTEDIT_SEG_SKIP) || halo > len)) {
+		if (!(sg->flags & NTEDIT_SEG_SKIP)) {
+			cs.rc = -8;
+		}
+		return; // (an entry that was superseded by a re-run: no output at all)
+	}
 	RNode root = { 0, 0, len ? len - 1 : 0, 0, 0 };
 	cs.nodes.push_back(root);
 	uint32_t cover = 0;
@@ -596,6 +661,18 @@ render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigO
 			chunk = next;
 		}
 	}
+	if (halo) {
+		// The last `halo` bases of the entry are look-ahead room that belongs to the next segment of the
+		// contig.  The cut is only valid if the serial run was clean again in front of it: every applied
+		// event ended at or before the cut, the rope ends in the open position node, nothing behind the
+		// cut was touched.
+		RNode& last = cs.nodes.back();
+		if (cover > len - halo || cs.terminated || last.type != 0 || last.e_pos != len - 1 || last.s_pos >= len - halo) {
+			cs.rc = -7;
+			return;
+		}
+		last.e_pos = len - 1 - halo;
+	}
 	const char* out_seq = seq;
 	if (!cs.seq.empty()) {
 		// the record's pieces will point into the modified copy: park it with the unit
@@ -606,20 +683,36 @@ render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigO
 	if (!any) {
 		// untouched contig: header + sequence + newline
 		if (v.want_fa) {
-			cs.fa_char('>');
-			cs.fa_text(v.names[ci], strlen(v.names[ci]));
-			cs.fa_char('\n');
-			cs.fa_span(seq, len);
-			cs.fa_char('\n');
+			if (!sg || !(sg->flags & NTEDIT_SEG_NO_HEADER)) {
+				cs.fa_char('>');
+				cs.fa_text(v.names[ci], strlen(v.names[ci]));
+				cs.fa_char('\n');
+			}
+			cs.fa_span(seq, len - halo);
+			if (!sg || !(sg->flags & NTEDIT_SEG_NO_NEWLINE)) {
+				cs.fa_char('\n');
+			}
 		}
 		return;
 	}
-	write_contig(v.names[ci], out_seq, cs, v.want_fa, v.want_tsv, v.want_vcf, v.opt);
+	write_contig(v.names[ci], out_seq, cs, v.want_fa, v.want_tsv, v.want_vcf, v.opt, sg, ci, v.want_edits);
 }
 
 int
-emit_contig(const ContigOut& o, FILE* fa, FILE* tsv, FILE* vcf, RenderStats* st)
+emit_contig(const ContigOut& o, FILE* fa, FILE* tsv, FILE* vcf, RenderStats* st, const RenderOptions& opt, uint32_t first_contig)
 {
+	if (opt.out_sizes && !o.sizes.empty()) {
+		memcpy(opt.out_sizes + (size_t)first_contig * 3, o.sizes.data(), o.sizes.size() * sizeof(uint64_t));
+	}
+	if (opt.edits && !o.edits.empty()) {
+		const size_t base = opt.edit_pool->size();
+		opt.edit_pool->append(o.edit_pool);
+		const size_t at = opt.edits->size();
+		opt.edits->insert(opt.edits->end(), o.edits.begin(), o.edits.end());
+		for (size_t i = at; i < opt.edits->size(); i++) {
+			(*opt.edits)[i].bases_off += (uint32_t)base;
+		}
+	}
 	if (fa && !o.fa.empty()) {
 		// the record is a gather of draft spans: hand them to the kernel as they are instead
 		// of copying everything through the stream's buffer first
@@ -680,6 +773,34 @@ emit_contig(const ContigOut& o, FILE* fa, FILE* tsv, FILE* vcf, RenderStats* st)
 
 } // namespace
 
+// The serial-order filter alone (what render_contig does before it renders): per entry, where the run of
+// the last applied event ended.
+int
+cover_ends(const Item* arena, size_t arena_items, const uint32_t* ev_first, size_t n_events, uint32_t n_contigs, uint32_t* out)
+{
+	for (uint32_t i = 0; i < n_contigs; i++) {
+		out[i] = 0;
+	}
+	for (size_t ev = 0; ev < n_events; ev++) {
+		const uint32_t fc = ev_first[ev];
+		if (fc == nte::NONE32) {
+			continue;
+		}
+		if ((size_t)fc * nte::CHUNK_ITEMS + 1 >= arena_items) {
+			return -1;
+		}
+		const Item& h = arena[(size_t)fc * nte::CHUNK_ITEMS + 1];
+		if (h.w[0] >= n_contigs) {
+			return -2;
+		}
+		if (h.w[1] < out[h.w[0]]) {
+			continue; // overtaken by an earlier event's serial run
+		}
+		out[h.w[0]] = h.w[2];
+	}
+	return 0;
+}
+
 void
 write_vcf_header(FILE* vcf, const char* draft_filename)
 {
@@ -737,6 +858,7 @@ render_batch(
 	v.want_tsv = tsv != nullptr;
 	v.want_vcf = vcf != nullptr;
 	v.opt = opt_in ? *opt_in : RenderOptions();
+	v.want_edits = v.opt.edits != nullptr && v.opt.edit_pool != nullptr;
 
 	// events of every contig: [ev_begin[ci], ev_begin[ci + 1])
 	std::vector<size_t> ev_begin((size_t)n_contigs + 1, 0);
@@ -787,7 +909,13 @@ render_batch(
 	auto render_unit = [&](uint32_t u, ContigOut& o) {
 		o.reset();
 		for (uint32_t ci = unit_begin[u]; ci < unit_begin[u + 1] && !o.rc; ci++) {
+			const size_t f0 = o.fa_bytes, t0 = o.tsv.size(), v0 = o.vcf.size();
 			render_contig(v, ci, ev_begin[ci], ev_begin[ci + 1], o);
+			if (v.opt.out_sizes) {
+				o.sizes.push_back(o.fa_bytes - f0);
+				o.sizes.push_back(o.tsv.size() - t0);
+				o.sizes.push_back(o.vcf.size() - v0);
+			}
 		}
 	};
 
@@ -808,7 +936,7 @@ render_batch(
 			if (o.rc) {
 				return o.rc;
 			}
-			if (int e = emit_contig(o, fa, tsv, vcf, st)) {
+			if (int e = emit_contig(o, fa, tsv, vcf, st, v.opt, unit_begin[u])) {
 				return e;
 			}
 		}
@@ -861,7 +989,7 @@ render_batch(
 			rc = o.rc;
 			break;
 		}
-		if ((rc = emit_contig(o, fa, tsv, vcf, st))) {
+		if ((rc = emit_contig(o, fa, tsv, vcf, st, v.opt, unit_begin[u]))) {
 			break;
 		}
 		{

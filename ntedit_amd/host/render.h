@@ -4,8 +4,10 @@
 // (ntedit.cpp:925-1213, headers 2175-2188).
 #pragma once
 #include "../csrc/nte_common.h"
+#include "../../include/ntedit_hip.h" // ntedit_hip_segment, ntedit_hip_edit (plain C structs)
 
 #include <cstdio>
+#include <string>
 #include <cstdint>
 #include <vector>
 
@@ -30,12 +32,20 @@ struct RenderOptions
 	const Annotations* annot = nullptr;
 	unsigned threads = 0;           // work units rendered concurrently (0 = up to 8, 1 = in the calling thread)
 	unsigned unit_bases = 1u << 20; // a work unit = consecutive contigs of about this many bases
+	// multi-GPU sharding: entry i is a segment of a larger contig (nullptr: every entry is a whole contig)
+	const ntedit_hip_segment* segments = nullptr;
+	uint64_t* out_sizes = nullptr;  // 3 per entry: bytes the entry added to the fa / tsv / vcf streams
+	// every _changes.tsv row (and, with -s 1, the VCF-only records) as POD records, in output order
+	std::vector<ntedit_hip_edit>* edits = nullptr;
+	std::string* edit_pool = nullptr; // inserted / deleted bases the records point into
 };
 
 // arena:    host copy of the chunk arena
 // ev_first: first chunk of every event, ordered by global start position (contig order, then
 //           position); nte::NONE32 entries (events without output) are skipped
 // fa / tsv: may be nullptr (that stream is skipped)
+// returns 0, or: -7 a segment's cut is not event-free (RenderOptions::segments), -8 bad segment descriptor,
+// -6 an event parked by the budget was not re-run, -1..-5 malformed records / write error
 int render_batch(
     const nte::Item* arena,
     size_t arena_items,
@@ -51,6 +61,9 @@ int render_batch(
     RenderStats* stats,
     FILE* vcf = nullptr,
     const RenderOptions* opt = nullptr);
+
+// per entry: where the serial run of its last applied event ended (0: no applied event)
+int cover_ends(const nte::Item* arena, size_t arena_items, const uint32_t* ev_first, size_t n_events, uint32_t n_contigs, uint32_t* out);
 
 // ntedit.cpp:2192-2211
 void write_vcf_header(FILE* vcf, const char* draft_filename);

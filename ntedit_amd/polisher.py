@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import NtEditHipError, Params, Stats
+from ._lib import NtEditHipError, Params, Stats, Segment, WriteOptions, EDIT_DTYPE
 
 PRIMARY, SECONDARY = 0, 1
 
@@ -55,22 +55,85 @@ class Result:
         self._lib.ntedit_hip_result_stats(self._h, ctypes.byref(s))
         return s
 
-    def write(self, blob, offsets, lens, names, fa_path, tsv_path, append=False, vcf_path=None, snv=False, annot=None):
+    @staticmethod
+    def _blob_ptr(blob):
+        """(keep-alive object, void*) of a host batch: numpy array (no copy), bytearray (no copy) or bytes"""
+        if isinstance(blob, np.ndarray):
+            buf = np.ascontiguousarray(blob, dtype=np.uint8)
+            return buf, ctypes.c_void_p(buf.ctypes.data)
+        if isinstance(blob, bytearray):
+            arr = (ctypes.c_char * max(len(blob), 1)).from_buffer(blob)
+            return arr, ctypes.cast(arr, ctypes.c_void_p)
+        buf = blob if isinstance(blob, bytes) else bytes(blob)
+        return buf, ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p)
+
+    @staticmethod
+    def _segment_array(segments, n):
+        """segments: None or a sequence of (pos_offset, halo, flags) per entry"""
+        if segments is None:
+            return None
+        arr = (Segment * max(n, 1))()
+        for i, (off, halo, flags) in enumerate(segments):
+            arr[i].pos_offset, arr[i].halo, arr[i].flags = int(off), int(halo), int(flags)
+        return arr
+
+    def write(self, blob, offsets, lens, names, fa_path, tsv_path, append=False, vcf_path=None, snv=False, annot=None,
+              segments=None, want_sizes=False):
+        """Render the batch (ntedit_hip_write_outputs_ex).  SNV mode follows the parameters the batch was polished
+        with (`snv` is ignored).  segments: per-entry (pos_offset, halo, flags) for contigs cut into segments.
+        want_sizes: return an (n, 3) uint64 array with the bytes every entry appended to fa / tsv / vcf."""
         n = len(names)
         arr = (ctypes.c_char_p * max(n, 1))(*names)
-        if isinstance(blob, np.ndarray):  # (large batches: no copy)
-            buf = np.ascontiguousarray(blob, dtype=np.uint8)
-            ptr = ctypes.c_void_p(buf.ctypes.data)
-        else:
-            buf = blob if isinstance(blob, (bytes, bytearray)) else bytes(blob)
-            ptr = ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p)
-        rc = self._lib.ntedit_hip_write_outputs_vcf(
-            self._h, ptr,
-            offsets.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), arr, n,
-            fa_path.encode() if fa_path else None, tsv_path.encode() if tsv_path else None,
-            vcf_path.encode() if vcf_path else None, 1 if append else 0, 1 if snv else 0, annot)
+        buf, ptr = self._blob_ptr(blob)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        seg = self._segment_array(segments, n)
+        sizes = np.zeros((max(n, 1), 3), dtype=np.uint64) if want_sizes else None
+        wo = WriteOptions()
+        wo.fa_path = fa_path.encode() if fa_path else None
+        wo.tsv_path = tsv_path.encode() if tsv_path else None
+        wo.vcf_path = vcf_path.encode() if vcf_path else None
+        wo.append = 1 if append else 0
+        wo.annot = annot
+        wo.segments = ctypes.cast(seg, ctypes.c_void_p) if seg is not None else None
+        wo.out_sizes = sizes.ctypes.data if sizes is not None else None
+        rc = self._lib.ntedit_hip_write_outputs_ex(
+            self._h, ptr, offsets.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), arr, n,
+            ctypes.byref(wo))
         if rc:
-            raise NtEditHipError("write_outputs failed (%d)" % rc)
+            raise NtEditHipError("write_outputs failed (%d)%s" % (
+                rc, ": a segment's cut is not event-free" if rc == _lib.E_SEGMENT else ""))
+        return sizes[:n] if sizes is not None else None
+
+    def cover_ends(self, n_contigs):
+        """per entry: where the serial run of its last applied event ended (0 = no applied event)"""
+        out = np.zeros(max(n_contigs, 1), dtype=np.uint32)
+        rc = self._lib.ntedit_hip_result_cover_ends(self._h, n_contigs, out.ctypes.data_as(ctypes.c_void_p))
+        if rc:
+            raise NtEditHipError("result_cover_ends failed (%d)" % rc)
+        return out[:n_contigs]
+
+    def edits(self, blob, offsets, lens, segments=None):
+        """(records, pool): every _changes.tsv row as a numpy record (dtype _lib.EDIT_DTYPE) plus the byte pool
+        the inserted / deleted bases live in"""
+        n = len(lens)
+        buf, ptr = self._blob_ptr(blob)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        seg = self._segment_array(segments, n)
+        ed, cnt, pool = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_void_p()
+        rc = self._lib.ntedit_hip_result_edits(
+            self._h, ptr, offsets.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), n,
+            ctypes.cast(seg, ctypes.c_void_p) if seg is not None else None, ctypes.byref(ed), ctypes.byref(cnt),
+            ctypes.byref(pool))
+        if rc:
+            raise NtEditHipError("result_edits failed (%d)" % rc)
+        dt = np.dtype(EDIT_DTYPE)
+        if cnt.value == 0:
+            return np.zeros(0, dtype=dt), b""
+        recs = np.frombuffer(ctypes.string_at(ed.value, cnt.value * dt.itemsize), dtype=dt).copy()
+        need = int((recs["bases_off"].astype(np.int64) + recs["len"]).max())
+        return recs, ctypes.string_at(pool.value, need)
 
     def free(self):
         if self._h:

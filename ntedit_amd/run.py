@@ -1,0 +1,210 @@
+"""python -m ntedit_amd.run -f draft.fa[.gz] -r solid.bf [-e repeat.bf] [-b prefix] [ntedit flags]
+
+The multi-GPU driver of the hot path: one process per GPU, launched with
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        -m ntedit_amd.run -f draft.fa -r solid.bf -b out
+
+(or plainly, without a launcher, on one GPU).  Rank 0 reads the Bloom filter file(s) once and ships the bit
+arrays to every GPU with ONE RCCL broadcast each (dist.load_and_broadcast_filter); every rank reads the draft,
+computes the same partition of the contigs by bases -- contigs larger than a GPU's share are cut at event-free
+boundaries (dist.plan_pieces) -- polishes its pieces through the C ABI (ntedit_amd.Polisher = libntedit_hip.so) and
+writes <prefix>.shard<r>_*; rank 0 gathers them into <prefix>_edited.fa / _changes.tsv / _variants.vcf in input
+order.  The output is byte-identical to the single-GPU `ntedit` binary's (and to the reference at -t 1).
+
+What the reference does instead: readAndCorrect's OpenMP loop (ntedit.cpp:2213-2252), contigs handed to threads one
+at a time, output in completion order."""
+import argparse
+import gzip
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import dist as ndist
+from .polisher import Polisher, default_params, pack_batch
+
+
+def read_fasta_fast(path):
+    """[(header, sequence bytes)] with kseq's record semantics (name + ' ' + comment; sequence = the lines joined,
+    lib/kseq.h:176-215 as used at ntedit.cpp:2223-2230).  Whole-file, C-speed string operations (a 3 GB draft
+    in seconds).  FASTQ input is handled by the `ntedit` binary's reader, not here."""
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "rb") as f:
+        data = f.read()
+    recs = []
+    if data.startswith(b">"):
+        pos = 0
+    else:  # (anything in front of the first header line is skipped, like kseq does)
+        i = data.find(b"\n>")
+        pos = i + 1 if i >= 0 else -1
+    n = len(data)
+    while 0 <= pos < n:
+        nxt = data.find(b"\n>", pos)
+        end = n if nxt < 0 else nxt + 1
+        eol = data.find(b"\n", pos, end)
+        if eol < 0:
+            eol = end
+        h = data[pos + 1:eol].rstrip(b"\r")
+        parts = h.split(None, 1)
+        name = parts[0] if parts else b""
+        rest = h[len(name) + 1:] if len(h) > len(name) else b""
+        hdr = name + (b" " + rest if rest else b"")
+        seq = data[eol + 1:end].replace(b"\n", b"").replace(b"\r", b"")
+        recs.append((hdr, seq))
+        pos = end if nxt >= 0 else n
+    return recs
+
+
+class HipBackend:
+    """dist.run_sharded's compute backend on the real thing: the HIP library through the C ABI"""
+
+    def __init__(self, polisher, annot=None):
+        self.pol = polisher
+        self.annot = annot
+        self.ms_gpu = 0.0
+        self.bases = 0
+        self.n_rerun = 0
+
+    def screen(self, blob):
+        return self.pol.screen(blob)
+
+    def polish(self, entries, fa, tsv, vcf, append):
+        names = [e[0] for e in entries]
+        blob, offs, lens, _ = pack_batch([(e[0], e[1]) for e in entries], 0)
+        res = self.pol.polish_batch(blob, offs, lens)
+        cover = res.cover_ends(len(entries))
+        segs, bad = [], []
+        for i, (_, _, (off, halo, flags)) in enumerate(entries):
+            if halo and int(cover[i]) > int(lens[i]) - halo:
+                bad.append(i)
+                flags |= ndist.SEG_SKIP
+            segs.append((off, halo, flags))
+        sizes = res.write(blob, offs, lens, names, fa, tsv, append=append, vcf_path=vcf, annot=self.annot,
+                          segments=segs, want_sizes=True)
+        st = res.stats()
+        self.ms_gpu += st.ms_total
+        self.bases += int(lens.sum())
+        self.n_rerun += len(bad)
+        res.free()
+        return bad, sizes
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m ntedit_amd.run", description=__doc__,
+                                 formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("-f", dest="draft", required=True)
+    ap.add_argument("-r", dest="bf", required=True)
+    ap.add_argument("-e", dest="bfrep")
+    ap.add_argument("-b", dest="prefix")
+    ap.add_argument("-l", dest="annot")
+    ap.add_argument("-z", dest="min_contig_len", type=int, default=100)
+    ap.add_argument("-i", dest="max_insertions", type=int, default=5)
+    ap.add_argument("-d", dest="max_deletions", type=int, default=5)
+    ap.add_argument("-x", dest="missing_threshold", type=float, default=5.0)
+    ap.add_argument("-y", dest="edit_threshold", type=float, default=9.0)
+    ap.add_argument("-X", dest="missing_ratio", type=float)
+    ap.add_argument("-Y", dest="edit_ratio", type=float)
+    ap.add_argument("-j", dest="jump", type=int, default=3)
+    ap.add_argument("-m", dest="mode", type=int, default=0)
+    ap.add_argument("-s", dest="snv", type=int, default=0)
+    ap.add_argument("-a", dest="mask", type=int, default=0)
+    ap.add_argument("-p", dest="min_threshold", type=int, default=1)
+    ap.add_argument("-q", dest="max_threshold", type=int, default=255)
+    ap.add_argument("-t", dest="threads", type=int, default=0, help="host threads rendering the output")
+    ap.add_argument("-k", dest="k_ignored", type=int, help="ignored: k comes from the filter")
+    ap.add_argument("--seg-bases", type=int, default=None,
+                    help="cut contigs longer than 1.5x this (default: a quarter of a GPU's share, 1-32 Mbp)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--report", action="store_true")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    args = parse(argv)
+    rank, world, local = ndist.env_rank()
+    if not torch.cuda.is_available():
+        sys.stderr.write("ntEdit v2.1.1: error: no HIP device (this build has no CPU path)\n")
+        return 1
+    torch.cuda.set_device(local)
+    if world > 1:
+        ndist.init_process_group(args.backend or "nccl")
+    elif args.backend:
+        # a one-rank group still exercises the collective path (the round-end GPU test does this)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        dist.init_process_group(backend=args.backend, rank=0, world_size=1)
+    pol = Polisher(local)
+    t0 = time.perf_counter()
+    ndist.load_and_broadcast_filter(pol, args.bf, 0, 0)
+    if args.bfrep:
+        ndist.load_and_broadcast_filter(pol, args.bfrep, 0, 1)
+    t_filter = time.perf_counter() - t0
+    k, h, nbytes, counting = pol.filter_info(0)
+    p = default_params(min_contig_len=args.min_contig_len, max_insertions=args.max_insertions,
+                       max_deletions=args.max_deletions, missing_threshold=args.missing_threshold,
+                       edit_threshold=args.edit_threshold, jump=args.jump, mode=args.mode, snv=args.snv,
+                       mask=args.mask, min_threshold=args.min_threshold if counting else 1,
+                       max_threshold=args.max_threshold)
+    if args.missing_ratio is not None or args.edit_ratio is not None:
+        p.use_ratio = 1
+        if args.missing_ratio is not None:
+            p.missing_ratio = args.missing_ratio
+        if args.edit_ratio is not None:
+            p.edit_ratio = args.edit_ratio
+    warn = ctypes.create_string_buffer(1024)
+    pol._lib.ntedit_hip_params_clamp(ctypes.byref(p), warn, 1024)  # ntedit.cpp:2478-2493
+    if warn.value and rank == 0:
+        sys.stderr.write(warn.value.decode())
+    pol.set_params(p)
+    if args.threads:
+        pol._lib.ntedit_hip_set_host_threads(args.threads)
+    prefix = args.prefix
+    if not prefix:  # ntedit.cpp:2496-2502
+        prefix = "%s_k%d_z%d_r%s_i%d_d%d_m%d" % (os.path.basename(args.draft), k, p.min_contig_len,
+                                                  os.path.basename(args.bf), p.max_insertions, p.max_deletions, p.mode)
+    annot = ctypes.c_void_p()
+    if args.annot:
+        if pol._lib.ntedit_hip_annot_load(args.annot.encode(), ctypes.byref(annot)):
+            sys.stderr.write("Unable to open file\n")
+            annot = ctypes.c_void_p()
+
+    t0 = time.perf_counter()
+    records = read_fasta_fast(args.draft)
+    t_read = time.perf_counter() - t0
+
+    def write_headers(pre):
+        open(pre + "_edited.fa", "wb").close()
+        pol.write_tsv_header(pre + "_changes.tsv")
+        pol._lib.ntedit_hip_write_vcf_header((pre + "_variants.vcf").encode(), args.draft.encode())
+
+    backend = HipBackend(pol, annot if annot.value else None)
+    halo = ndist.halo_bases(k, 0 if p.snv else p.max_insertions, 0 if p.snv else p.max_deletions)
+    barrier = dist.barrier if (dist.is_initialized() and world > 1) else None
+    t0 = time.perf_counter()
+    mine = ndist.run_sharded(records, backend, prefix, p.min_contig_len, rank, world, k, halo, write_headers,
+                             barrier=barrier, seg_bases=args.seg_bases)
+    if barrier:
+        barrier()
+    t_run = time.perf_counter() - t0
+    if args.report:
+        n_seg = sum(1 for q in mine if q.n_seg > 1)
+        sys.stdout.write('{"rank": %d, "world": %d, "pieces": %d, "segments": %d, "bases": %d, "reruns": %d, '
+                         '"gpu_ms": %.3f, "filter_s": %.3f, "read_s": %.3f, "run_s": %.3f}\n' %
+                         (rank, world, len(mine), n_seg, backend.bases, backend.n_rerun, backend.ms_gpu, t_filter,
+                          t_read, t_run))
+        sys.stdout.flush()
+    if annot.value:
+        pol._lib.ntedit_hip_annot_free(annot)
+    pol.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -383,6 +383,10 @@ ora_bf_load(ora_bf* bf, const char* path)
 		ora_bf_free(bf);
 		return -4;
 	}
+	/* btllib's file constructor takes the header's size as it is (array_size = bytes, array_bits =
+	 * bytes * 8); only its BUILD constructor rounds up to 8 bytes (ora_bf_init) */
+	bf->bytes = bytes;
+	bf->bits = bytes * 8;
 	return 0;
 }
 

@@ -526,3 +526,39 @@ def make_many_case(tmp, n_contigs=3000, mean_len=500, seed=7):
         draft.append((b"frag%d" % i if i % 3 else b"frag%d note" % i, bytes(d)))
     write_fasta(os.path.join(tmp, "draft.fa"), draft, width=0)
     return {"draft": os.path.join(tmp, "draft.fa"), "bf": os.path.join(tmp, "t.bf"), "rep": None}
+
+
+def tsv_from_edits(recs, pool, names, header_line):
+    """_changes.tsv text rebuilt from ntedit_hip_edit records (numpy, dtype ntedit_amd._lib.EDIT_DTYPE) and the
+    base pool: the inverse of the C ABI's edit-record accessor, used to check it against the file the renderer
+    writes (row formats: ntedit.cpp:1013-1029 insertions, 1113-1150 substitutions, 1173-1183 deletions)."""
+    out = [header_line]
+    for e in recs:
+        kind = int(e["kind"])
+        name = names[int(e["contig"])]
+        if kind == 4:  # SNV mode: position kept, VCF-only
+            continue
+        if kind == 1:
+            row = [name, b"%d" % (int(e["draft_pos"]) + 1), bytes([int(e["draft_base"])]), bytes([int(e["new_base"])]),
+                   b"%d" % int(e["support"])]
+            for j in range(int(e["n_alt"])):
+                row += [bytes([int(e["alt_base"][j])]), b"%d" % int(e["alt_support"][j])]
+        else:
+            bases = pool[int(e["bases_off"]):int(e["bases_off"]) + int(e["len"])]
+            bases = bases.split(b"\0")[0]  # (the reference prints through c_str())
+            row = [name, b"%d" % int(e["draft_pos"]), bytes([int(e["draft_base"])]), (b"+" if kind == 2 else b"-") + bases,
+                   b"%d" % int(e["support"])]
+        out.append(b"\t".join(row) + b"\n")
+    return b"".join(out)
+
+
+def load_edits_dump(path):
+    """the test-only dump of hostsim_set_render_extras(edits_path): u64 count | records | u64 pool bytes | pool"""
+    from ntedit_amd._lib import EDIT_DTYPE
+    raw = open(path, "rb").read()
+    dt = np.dtype(EDIT_DTYPE)
+    n = int(np.frombuffer(raw[:8], dtype="<u8")[0])
+    recs = np.frombuffer(raw[8:8 + n * dt.itemsize], dtype=dt)
+    o = 8 + n * dt.itemsize
+    npool = int(np.frombuffer(raw[o:o + 8], dtype="<u8")[0])
+    return recs, raw[o + 8:o + 8 + npool]

@@ -17,6 +17,7 @@ namespace nte { WorkCounters g_wc; }
 
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 using namespace nte;
@@ -77,6 +78,25 @@ hostsim_screen(
 	Filter f = make_filter(bf, bf_bytes, hash_num, counting != 0);
 	sim_screen((const u8*)bases, n, f, p, tab, bitmap);
 	return 0;
+}
+
+// TEST-ONLY: extras for the NEXT hostsim_polish call (cleared by it): segment descriptors, per-entry output
+// sizes and cover ends (the multi-GPU gather's inputs), flag 1 = no TSV / VCF header lines (shard files),
+// and a file that receives the ntedit_hip_edit records: u64 count | records | u64 pool bytes | pool.
+static const ntedit_hip_segment* g_x_segments = nullptr;
+static uint64_t* g_x_sizes = nullptr;
+static uint32_t* g_x_covers = nullptr;
+static unsigned g_x_flags = 0;
+static std::string g_x_edits_path;
+
+extern "C" void
+hostsim_set_render_extras(const ntedit_hip_segment* segments, uint64_t* sizes, uint32_t* covers, unsigned flags, const char* edits_path)
+{
+	g_x_segments = segments;
+	g_x_sizes = sizes;
+	g_x_covers = covers;
+	g_x_flags = flags;
+	g_x_edits_path = edits_path ? edits_path : "";
 }
 
 extern "C" int
@@ -254,14 +274,33 @@ hostsim_polish(
 	}
 	FILE* fa = fa_path ? fopen(fa_path, "w") : nullptr;
 	FILE* tsv = tsv_path ? fopen(tsv_path, "w") : nullptr;
-	if (tsv) {
+	if (tsv && !(g_x_flags & 1)) {
 		nte_host::write_tsv_header(tsv, k, hp->jump, counting != 0);
 	}
 	FILE* vcf = vcf_path ? fopen(vcf_path, "w") : nullptr;
-	if (vcf) {
+	if (vcf && !(g_x_flags & 1)) {
 		nte_host::write_vcf_header(vcf, "draft");
 	}
 	nte_host::RenderOptions ropt;
+	std::vector<ntedit_hip_edit> x_edits;
+	std::string x_pool;
+	ropt.segments = g_x_segments;
+	ropt.out_sizes = g_x_sizes;
+	if (g_x_covers) {
+		// (the serial-order filter alone, as ntedit_hip_result_cover_ends does it)
+		if (nte_host::cover_ends(arena.data(), arena.size(), ev_first.data(), ev_first.size(), n_contigs, g_x_covers)) {
+			return -9;
+		}
+	}
+	if (g_x_sizes) {
+		memset(g_x_sizes, 0, (size_t)n_contigs * 3 * sizeof(uint64_t));
+	}
+	const std::string x_edits_path = g_x_edits_path;
+	if (!x_edits_path.empty()) {
+		ropt.edits = &x_edits;
+		ropt.edit_pool = &x_pool;
+	}
+	hostsim_set_render_extras(nullptr, nullptr, nullptr, 0, nullptr);
 	if (const char* rt = getenv("HOSTSIM_RENDER_THREADS")) {
 		ropt.threads = (unsigned)atoi(rt);
 	}
@@ -287,6 +326,16 @@ hostsim_polish(
 	    &st,
 	    vcf,
 	    &ropt);
+	if (!x_edits_path.empty()) {
+		if (FILE* ef = fopen(x_edits_path.c_str(), "wb")) {
+			const uint64_t ne = x_edits.size(), np = x_pool.size();
+			fwrite(&ne, 8, 1, ef);
+			fwrite(x_edits.data(), sizeof(ntedit_hip_edit), x_edits.size(), ef);
+			fwrite(&np, 8, 1, ef);
+			fwrite(x_pool.data(), 1, x_pool.size(), ef);
+			fclose(ef);
+		}
+	}
 	if (vcf) {
 		fclose(vcf);
 	}

@@ -1,12 +1,13 @@
-"""N>1 path on CPU: world_size-2 gloo run of the filter broadcast + contig
-sharding + host-side gather; the merged output must equal the single-process
-oracle output byte for byte (input order = reference at -t 1)."""
+"""N>1 path on CPU: world_size-2 gloo runs of the filter broadcast + partition by bases (contigs cut into
+segments at event-free boundaries) + host-side gather by index; the merged output must equal the
+single-process oracle output byte for byte (input order = reference at -t 1)."""
 import filecmp
 import os
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 import helpers as H
 from ntedit_amd import dist as ndist
@@ -26,19 +27,106 @@ def test_shard_contigs_balances_by_bases():
     assert list(ndist.shard_contigs(lens, 1, 0)[0]) == list(range(8))
 
 
-def test_two_rank_gloo_run_matches_oracle(tmp_path, oracle_build):
-    case = H.make_case(str(tmp_path), 909, contigs=5, n=30000, flavor="N")
-    hp = H.default_params()
-    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"))
+def _bf_case(tmp_path, seed, **kw):
+    case = H.make_case(str(tmp_path), seed, **kw)
+    return case, H.load_bf(case["bf"]), H.read_fasta(case["draft"])
+
+
+def test_refine_cut_lands_in_a_clean_stretch(tmp_path, oracle_build):
+    """a refined cut has lead k-mers in the filter in front of it and a halo of them behind it; it is a function
+    of the draft and the filter only"""
+    case, bf, recs = _bf_case(tmp_path, 515, contigs=1, n=40000, p_sub=5e-3, flavor="N")
+    k = bf["k"]
+    seq = recs[0][1]
+    halo = ndist.halo_bases(k, 5, 5)
+    lead = ndist.lead_bases(k)
+    screen = lambda b: H.oracle_screen(b, bf)  # noqa: E731
+    whole = np.unpackbits(screen(seq).view(np.uint8), bitorder="little").astype(bool)
+    n_cut = 0
+    for nominal in range(1000, len(seq) - 3000, 1777):
+        c = ndist.refine_cut(seq, nominal, k, halo, screen, window=2048)
+        if c is None:
+            continue
+        n_cut += 1
+        assert nominal + lead <= c < nominal + 2048
+        lo, hi = c - lead, c + halo - k
+        assert not whole[lo:hi + 1].any()
+        assert set(seq[lo:hi + k]) <= set(b"ACGTacgt")
+        assert c == ndist.refine_cut(seq, nominal, k, halo, screen, window=2048)
+    assert n_cut > 10
+    # no clean stretch inside the window -> no cut; window running off the contig -> no cut
+    assert ndist.refine_cut(seq, 1000, k, halo, lambda b: np.full((len(b) + 63) // 64, ~np.uint64(0)), window=2048) is None
+    assert ndist.refine_cut(seq, len(seq) - 100, k, halo, screen) is None
+
+
+def test_plan_pieces_cuts_large_contigs_and_balances(tmp_path, oracle_build):
+    case, bf, recs = _bf_case(tmp_path, 516, contigs=3, n=50000)
+    k = bf["k"]
+    halo = ndist.halo_bases(k, 5, 5)
+    screen = lambda b: H.oracle_screen(b, bf)  # noqa: E731
+    pieces = ndist.plan_pieces(recs, 4, 100, k, halo, screen, seg_bases=9000)
+    # the 40-base record is below -z; every other contig is covered exactly once, in order
+    by = {}
+    for p in pieces:
+        by.setdefault(p.contig, []).append(p)
+    assert sorted(by) == [0, 1, 2]
+    for ci, ps in by.items():
+        assert ps[0].start == 0 and ps[-1].end == len(recs[ci][1]) and len(ps) >= 4
+        assert all(a.end == b.start for a, b in zip(ps, ps[1:]))
+        assert [p.seg for p in ps] == list(range(len(ps))) and all(p.n_seg == len(ps) for p in ps)
+    load = [sum(p.end - p.start for p in pieces if p.owner == r) for r in range(4)]
+    assert max(load) - min(load) <= max(p.end - p.start for p in pieces)  # LPT: within one piece
+    # deterministic
+    again = ndist.plan_pieces(recs, 4, 100, k, halo, screen, seg_bases=9000)
+    assert [(p.contig, p.start, p.end, p.owner) for p in again] == [(p.contig, p.start, p.end, p.owner) for p in pieces]
+    # one rank: no cuts
+    assert all(p.n_seg == 1 for p in ndist.plan_pieces(recs, 1, 100, k, halo, screen))
+
+
+def _two_ranks(tmp_path, case, extra):
     env = dict(os.environ)
     env["MASTER_ADDR"] = "127.0.0.1"
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(H.ROOT, "tests", "dist_worker.py"), case["draft"], case["bf"], str(tmp_path / "d")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+           os.path.join(H.ROOT, "tests", "dist_worker.py"), case["draft"], case["bf"], str(tmp_path / "d")] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
     assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "d_edited.fa"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "d_changes.tsv"), shallow=False)
-    assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "d_variants.vcf"))
+    body = [l for l in open(str(tmp_path / "o_variants.vcf")).read().splitlines() if not l.startswith("#")]
+    assert open(str(tmp_path / "d_variants.vcf")).read().splitlines() == body
     assert not [f for f in os.listdir(str(tmp_path)) if ".shard" in f]
+    return [[int(x) for x in l.split()] for l in open(str(tmp_path / "d.stats")).read().splitlines()]
+
+
+def test_two_rank_gloo_run_matches_oracle(tmp_path, oracle_build):
+    case = H.make_case(str(tmp_path), 909, contigs=5, n=30000, flavor="N")
+    H.run_oracle(case["draft"], case["bf"], H.default_params(), str(tmp_path / "o"))
+    stats = _two_ranks(tmp_path, case, [])
+    assert sum(s[0] for s in stats) == 5 and all(s[1] == 0 for s in stats)  # whole contigs only
+
+
+def test_two_rank_split_contigs_reassemble_byte_identically(tmp_path, oracle_build):
+    """contigs far larger than a rank's share are cut into segments at event-free boundaries, the segments are
+    polished on different ranks, and the gather re-assembles every contig byte-identically"""
+    case = H.make_case(str(tmp_path), 910, contigs=2, n=90000, flavor="N lower", p_sub=4e-3, p_ins=6e-4, p_del=6e-4,
+                       bfbytes=1 << 21)
+    H.run_oracle(case["draft"], case["bf"], H.default_params(), str(tmp_path / "o"))
+    stats = _two_ranks(tmp_path, case, ["7000"])
+    assert all(s[1] >= 5 for s in stats)  # both ranks polished segments
+    loads = [s[3] for s in stats]
+    assert abs(loads[0] - loads[1]) < 0.1 * sum(loads)
+    # refined cuts verify (a cut can still fail where an edit chain runs through the clean stretch -- the small,
+    # false-positive-rich filters of the other tests provoke that -- and is then re-run like a blind one)
+    assert sum(s[2] for s in stats) == 0
+
+
+def test_two_rank_bad_cuts_are_caught_and_rerun(tmp_path, oracle_build):
+    """cuts placed blindly (the planner is told every k-mer is in the filter) in an error-dense draft: the
+    library's verification rejects the segments whose cut is not event-free, they are re-run joined with their
+    successors, and the result is still byte-identical"""
+    case = H.make_case(str(tmp_path), 911, contigs=2, n=60000, p_sub=2e-2, p_ins=3e-3, p_del=3e-3)
+    H.run_oracle(case["draft"], case["bf"], H.default_params(), str(tmp_path / "o"))
+    stats = _two_ranks(tmp_path, case, ["3000", "blind"])
+    assert sum(s[2] for s in stats) > 0  # some cuts were rejected

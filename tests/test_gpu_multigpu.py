@@ -1,0 +1,214 @@
+"""GPU tests of what round 2 added around the hot path: the multi-GPU driver (python -m ntedit_amd.run) over
+RCCL at world_size 1, contigs cut into segments and re-assembled, the edit-record accessor of the C ABI, and
+filter files whose size is not a multiple of 8.  Through the C ABI; compared with the oracle byte for byte."""
+import filecmp
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_outputs(o, g):
+    assert filecmp.cmp(o + "_changes.tsv", g + "_changes.tsv", shallow=False)
+    assert filecmp.cmp(o + "_edited.fa", g + "_edited.fa", shallow=False)
+    assert H.vcf_body(o + "_variants.vcf") == H.vcf_body(g + "_variants.vcf")
+
+
+def test_edit_records_through_the_c_abi(tmp_path, oracle_build):
+    """ntedit_hip_result_edits(): the POD records rebuild the _changes.tsv the library writes (modes 0-2, -s 1,
+    secondary filter, counting filter)"""
+    import ntedit_amd
+    for ci in (0, 5, 8, 9, 22, 29, 33):
+        case_kw, par_kw = H.PARITY_CONFIGS[ci]
+        d = tmp_path / ("c%d" % ci)
+        case = H.make_case(str(d), 8200 + ci, **case_kw)
+        recs = H.read_fasta(case["draft"])
+        pol = ntedit_amd.Polisher(0)
+        try:
+            pol.load_filter_file(case["bf"], 0)
+            if case["rep"]:
+                pol.load_filter_file(case["rep"], 1)
+            pol.set_params(ntedit_amd.default_params(**par_kw))
+            blob, offs, lens, names = ntedit_amd.pack_batch(recs, pol.params.min_contig_len)
+            res = pol.polish_batch(blob, offs, lens)
+            edits, pool = res.edits(blob, offs, lens)
+            tsv = str(d / "g_changes.tsv")
+            pol.write_tsv_header(tsv)
+            res.write(blob, offs, lens, names, None, tsv, append=True)
+            st = res.stats()
+            res.free()
+        finally:
+            pol.close()
+        text = open(tsv, "rb").read()
+        header = text[:text.index(b"\n") + 1]
+        assert H.tsv_from_edits(edits, pool, names, header) == text, ci
+        n_rows = text.count(b"\n") - 1
+        assert n_rows == int((edits["kind"] != 4).sum()) and n_rows > 5
+        assert st.substitutions + st.insertions + st.deletions == n_rows
+
+
+def _hip_backend_two_ranks(tmp_path, case, par_kw, seg_bases, blind=False):
+    """both "ranks" of a 2-way sharded run, one after the other on the one GPU (rank 1 first: rank 0 gathers)"""
+    import ntedit_amd
+    from ntedit_amd import dist as ndist
+    from ntedit_amd.run import HipBackend
+    recs = H.read_fasta(case["draft"])
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.load_filter_file(case["bf"], 0)
+        if case["rep"]:
+            pol.load_filter_file(case["rep"], 1)
+        pol.set_params(ntedit_amd.default_params(**par_kw))
+        k = pol.filter_info(0)[0]
+        p = pol.params
+        halo = ndist.halo_bases(k, p.max_insertions, p.max_deletions)
+        prefix = str(tmp_path / "g")
+
+        def write_headers(pre):
+            open(pre + "_edited.fa", "wb").close()
+            pol.write_tsv_header(pre + "_changes.tsv")
+            pol._lib.ntedit_hip_write_vcf_header((pre + "_variants.vcf").encode(), b"draft")
+
+        class Blind(HipBackend):
+            def screen(self, blob):
+                return np.zeros((len(blob) + 63) // 64, dtype=np.uint64)
+
+        stats = []
+        for rank in (1, 0):
+            be = (Blind if blind else HipBackend)(pol)
+            mine = ndist.run_sharded(recs, be, prefix, p.min_contig_len, rank, 2, k, halo, write_headers,
+                                     seg_bases=seg_bases)
+            stats.append((len(mine), sum(1 for q in mine if q.n_seg > 1), be.n_rerun, be.bases))
+    finally:
+        pol.close()
+    assert not [f for f in os.listdir(str(tmp_path)) if ".shard" in f]
+    return stats
+
+
+@pytest.mark.parametrize("ci", [0, 5, 8, 22])
+def test_segments_reassemble_on_gpu(tmp_path, ci, oracle_build):
+    """contigs cut into segments (polished as separate batch entries with look-ahead halos, verified from the edit
+    records) re-assemble byte-identically"""
+    case_kw, par_kw = H.PARITY_CONFIGS[ci]
+    case_kw = dict(case_kw, contigs=2, n=80000, bfbytes=1 << 21)
+    case = H.make_case(str(tmp_path), 8300 + ci, **case_kw)
+    H.run_oracle(case["draft"], case["bf"], H.default_params(**par_kw), str(tmp_path / "o"), case["rep"])
+    stats = _hip_backend_two_ranks(tmp_path, case, par_kw, 9000)
+    _same_outputs(str(tmp_path / "o"), str(tmp_path / "g"))
+    assert all(s[1] >= 3 for s in stats)
+    assert abs(stats[0][3] - stats[1][3]) < 0.15 * (stats[0][3] + stats[1][3])
+
+
+def test_bad_cuts_are_rejected_and_rerun_on_gpu(tmp_path, oracle_build):
+    case = H.make_case(str(tmp_path), 8400, contigs=2, n=60000, p_sub=2e-2, p_ins=3e-3, p_del=3e-3)
+    H.run_oracle(case["draft"], case["bf"], H.default_params(), str(tmp_path / "o"))
+    stats = _hip_backend_two_ranks(tmp_path, case, {}, 3000, blind=True)
+    _same_outputs(str(tmp_path / "o"), str(tmp_path / "g"))
+    assert sum(s[2] for s in stats) > 0
+    # a segment whose cut is not event-free is refused by the renderer itself
+    import ntedit_amd
+    from ntedit_amd import dist as ndist
+    recs = [r for r in H.read_fasta(case["draft"]) if len(r[1]) > 1000]
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.load_filter_file(case["bf"], 0)
+        pol.set_params(ntedit_amd.default_params())
+        halo = ndist.halo_bases(25, 5, 5)
+        seq = recs[0][1]
+        refused = 0
+        for cut in range(2000, 20000, 500):
+            blob, offs, lens, names = ntedit_amd.pack_batch([(recs[0][0], seq[:cut + halo])], 0)
+            res = pol.polish_batch(blob, offs, lens)
+            cover = int(res.cover_ends(1)[0])
+            try:
+                res.write(blob, offs, lens, names, str(tmp_path / "x.fa"), None, segments=[(0, halo, ndist.SEG_NO_NEWLINE)])
+                assert cover <= cut
+                assert open(str(tmp_path / "x.fa"), "rb").read().count(b"\n") == 1  # header line only
+            except ntedit_amd.NtEditHipError as e:
+                assert cover > cut and "(-7)" in str(e)
+                refused += 1
+            res.free()
+        assert refused > 0
+    finally:
+        pol.close()
+
+
+def test_run_driver_over_rccl_world_1(tmp_path, oracle_build):
+    """python -m ntedit_amd.run: the multi-GPU driver end to end at world_size 1 over the nccl (= RCCL) backend:
+    filter files read by rank 0 and broadcast, draft partitioned (contigs cut: --seg-bases), pieces polished through
+    the C ABI, shard files gathered by index -- byte-identical to the oracle; gzipped draft, -e, -l-less VCF"""
+    import gzip
+    import shutil
+    case = H.make_case(str(tmp_path), 8500, flavor="sec N lower", contigs=3, n=70000, bfbytes=1 << 21)
+    gz = str(tmp_path / "draft.fa.gz")
+    with open(case["draft"], "rb") as fi, gzip.open(gz, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    hp = H.default_params(max_insertions=4, max_deletions=7, mode=1, min_contig_len=50)
+    H.run_oracle(gz, case["bf"], hp, str(tmp_path / "o"), case["rep"])
+    env = dict(os.environ)
+    env["PYTHONPATH"] = H.ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(29700 + os.getpid() % 200)
+    cmd = [sys.executable, "-m", "ntedit_amd.run", "-f", gz, "-r", case["bf"], "-e", case["rep"], "-b", str(tmp_path / "g"),
+           "-i", "4", "-d", "7", "-m", "1", "-z", "50", "--seg-bases", "11000", "--backend", "nccl", "--report"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    _same_outputs(str(tmp_path / "o"), str(tmp_path / "g"))
+    import json
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["world"] == 1 and rep["segments"] >= 9 and rep["bases"] >= 210000
+    # the same through the launcher the driver is started with on N GPUs
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), "-m", "ntedit_amd.run", "-f", case["draft"], "-r", case["bf"],
+           "-b", str(tmp_path / "t"), "-i", "4", "-d", "7", "-m", "1", "-z", "50", "-e", case["rep"]]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "t_changes.tsv"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "t_edited.fa"), shallow=False)
+
+
+def test_filter_file_size_not_a_multiple_of_8_gpu(tmp_path, oracle_build):
+    import ntedit_amd
+    case = H.make_case(str(tmp_path), 8100, n=20000, contigs=2, bfbytes=1 << 16)
+    raw = open(case["bf"], "rb").read()
+    body = raw.index(b"[HeaderEnd]\n") + len(b"[HeaderEnd]\n")
+    odd = (1 << 16) - 3
+    with open(str(tmp_path / "odd.bf"), "wb") as f:
+        f.write(raw[:body].replace(b"bytes = %d" % (1 << 16), b"bytes = %d" % odd))
+        f.write(raw[body:body + odd])
+    hp = H.default_params()
+    H.run_oracle(case["draft"], str(tmp_path / "odd.bf"), hp, str(tmp_path / "o"))
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.load_filter_file(str(tmp_path / "odd.bf"))
+        assert pol.filter_info(0)[2] == odd
+        pol.set_params(ntedit_amd.default_params())
+        pol.polish_records(H.read_fasta(case["draft"]), str(tmp_path / "g"))
+        occ, slots = pol.filter_occupancy(0)
+        bits = pol.filter_download(0)
+        assert slots == odd * 8 and bits.size == odd and occ == int(np.unpackbits(bits).sum())
+        # set_filter with the same odd-sized array
+        pol.set_filter(bits, 3, 25)
+        pol.polish_records(H.read_fasta(case["draft"]), str(tmp_path / "g2"))
+    finally:
+        pol.close()
+    _same_outputs(str(tmp_path / "o"), str(tmp_path / "g"))
+    _same_outputs(str(tmp_path / "o"), str(tmp_path / "g2"))
+    # header validation (clear messages, at load time)
+    bad = raw[:body].replace(b'"ntHash_v2"', b'"murmur"') + raw[body:]
+    open(str(tmp_path / "bad.bf"), "wb").write(bad)
+    pol = ntedit_amd.Polisher(0)
+    try:
+        with pytest.raises(ntedit_amd.NtEditHipError, match="hash_fn"):
+            pol.load_filter_file(str(tmp_path / "bad.bf"))
+        open(str(tmp_path / "k5.bf"), "wb").write(raw[:body].replace(b"k = 25", b"k = 5") + raw[body:])
+        with pytest.raises(ntedit_amd.NtEditHipError, match="k = 5"):
+            pol.load_filter_file(str(tmp_path / "k5.bf"))
+    finally:
+        pol.close()

@@ -3,6 +3,8 @@ nte_machine.h / render.cpp, tests/hostsim) against the oracle, byte for byte.
 Same configurations as the GPU parity test."""
 import filecmp
 
+import numpy as np
+
 import pytest
 
 import helpers as H
@@ -131,3 +133,55 @@ def test_many_short_contigs(tmp_path, oracle_build, monkeypatch, unit, threads, 
     for suf in ("_changes.tsv", "_edited.fa"):
         assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("h" + suf)), shallow=False), suf
     assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))
+
+
+@pytest.mark.parametrize("ci", [0, 5, 9, 10, 22, 28, 31])
+def test_edit_records_rebuild_the_tsv(tmp_path, ci, oracle_build):
+    """the POD edit records of the C ABI (ntedit_hip_result_edits; here straight from the product's renderer on
+    the host simulation) carry exactly what the _changes.tsv rows say"""
+    import ctypes
+    case_kw, par_kw = H.PARITY_CONFIGS[ci]
+    case = H.make_case(str(tmp_path), 8000 + ci, **case_kw)
+    bf = H.load_bf(case["bf"])
+    rep = H.load_bf(case["rep"]) if case["rep"] else None
+    hp = H.default_params(**par_kw)
+    recs = H.read_fasta(case["draft"])
+    dump = str(tmp_path / "edits.bin")
+    H.hostsim_lib().hostsim_set_render_extras(None, None, None, ctypes.c_uint(0), dump.encode())
+    rc, _, _ = H.run_hostsim(recs, bf, hp, str(tmp_path / "h"), rep)
+    assert rc == 0
+    edits, pool = H.load_edits_dump(dump)
+    names = [n for n, s in recs if len(s) >= hp.min_contig_len]
+    tsv = open(str(tmp_path / "h_changes.tsv"), "rb").read()
+    header = tsv[:tsv.index(b"\n") + 1]
+    assert H.tsv_from_edits(edits, pool, names, header) == tsv
+    assert len(edits) > 5
+    kinds = set(int(x) for x in edits["kind"])
+    assert kinds <= {1, 2, 3, 4} and 1 in kinds
+    # positions are non-decreasing within a contig
+    for c in set(int(x) for x in edits["contig"]):
+        pos = edits["draft_pos"][edits["contig"] == c].astype(np.int64)
+        assert (np.diff(pos) >= -1).all()
+
+
+def test_filter_file_size_not_a_multiple_of_8(tmp_path, oracle_build):
+    """a .bf whose `bytes` is not a multiple of 8: the header's size IS the modulus of the slot arithmetic (btllib's
+    file constructor takes it as it is; only filters it builds are rounded up)"""
+    case = H.make_case(str(tmp_path), 8100, n=20000, contigs=2, bfbytes=1 << 16)
+    raw = open(case["bf"], "rb").read()
+    body = raw.index(b"[HeaderEnd]\n") + len(b"[HeaderEnd]\n")
+    odd = (1 << 16) - 3
+    with open(str(tmp_path / "odd.bf"), "wb") as f:
+        f.write(raw[:body].replace(b"bytes = %d" % (1 << 16), b"bytes = %d" % odd))
+        f.write(raw[body:body + odd])
+    bf = H.load_bf(str(tmp_path / "odd.bf"))
+    assert bf["bytes"] == odd and bf["data"].size == odd
+    hp = H.default_params()
+    H.run_oracle(case["draft"], str(tmp_path / "odd.bf"), hp, str(tmp_path / "o"))
+    rc, _, _ = H.run_hostsim(H.read_fasta(case["draft"]), bf, hp, str(tmp_path / "h"))
+    assert rc == 0
+    assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "h_changes.tsv"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "h_edited.fa"), shallow=False)
+    # and it is NOT what the rounded-up modulus gives
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "r"))
+    assert not filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "r_changes.tsv"), shallow=False)

@@ -128,6 +128,12 @@ int ntedit_hip_set_params(ntedit_hip_ctx* ctx, const ntedit_hip_params* p);
  * least one byte that is not an accepted base (the host driver uses '\n').
  * n = total bytes.  on_device != 0 means `bases` is already in HBM. */
 
+/* Page-locked host memory for batches (optional): a batch handed over from such a buffer crosses PCIe
+ * asynchronously, in pieces, while the pieces already in HBM are being screened.  Any other host memory
+ * works too (staged by the runtime).  NULL when there is no device / no memory. */
+void* ntedit_hip_host_alloc(size_t bytes);
+void ntedit_hip_host_free(void* p);
+
 /* step 1 only (ntedit.cpp:1798-1807): bit i of bitmap (ceil(n/64) words,
  * host memory, or device memory when on_device) is set iff the k-mer starting
  * at byte i consists of accepted bases only and is NOT in the primary filter. */

@@ -101,6 +101,7 @@ EXPORTS = [
     "ntedit_hip_annot_load", "ntedit_hip_annot_free", "ntedit_hip_write_vcf_header", "ntedit_hip_write_outputs_vcf",
     "ntedit_hip_set_host_threads", "ntedit_hip_filter_occupancy",
     "ntedit_hip_write_outputs_ex", "ntedit_hip_result_cover_ends", "ntedit_hip_result_edits",
+    "ntedit_hip_host_alloc", "ntedit_hip_host_free",
 ]
 
 _lib = None
@@ -157,6 +158,10 @@ def load():
     lib.ntedit_hip_result_cover_ends.argtypes = [vp, u32, vp]
     lib.ntedit_hip_result_edits.argtypes = [vp, vp, vp, vp, u32, vp, ctypes.POINTER(vp), ctypes.POINTER(u64),
                                             ctypes.POINTER(vp)]
+    lib.ntedit_hip_host_alloc.argtypes = [ctypes.c_size_t]
+    lib.ntedit_hip_host_alloc.restype = vp
+    lib.ntedit_hip_host_free.argtypes = [vp]
+    lib.ntedit_hip_host_free.restype = None
     lib.ntedit_hip_filter_occupancy.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.ntedit_hip_set_host_threads.argtypes = [ctypes.c_uint]
     lib.ntedit_hip_set_host_threads.restype = None

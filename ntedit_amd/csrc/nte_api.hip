@@ -72,6 +72,7 @@ struct ntedit_hip_ctx
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr; // event extraction + machine of the chunk pipeline
 	std::vector<hipEvent_t> chunk_ev; // 2 per chunk on `stream` (screen begin / end)
+	std::vector<hipEvent_t> h2d_ev;   // one per host-to-device piece of a host-resident batch
 	DevFilter filt[2];
 	ntedit_hip_params hp;
 	DevParams dp;
@@ -545,7 +546,7 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 
 // copies (or adopts) the batch into HBM; returns the device pointer
 int
-stage_bases(ntedit_hip_ctx* c, const char* bases, u64 n, int on_device, const u8** out)
+stage_bases(ntedit_hip_ctx* c, const char* bases, u64 n, int on_device, const u8** out, bool copy = true)
 {
 	if (on_device) {
 		if ((uintptr_t)bases & 15) {
@@ -558,7 +559,9 @@ stage_bases(ntedit_hip_ctx* c, const char* bases, u64 n, int on_device, const u8
 	if (rc) {
 		return rc;
 	}
-	HIP_TRY(c, hipMemcpyAsync(c->seq.p, bases, n, hipMemcpyHostToDevice, c->stream));
+	if (copy) {
+		HIP_TRY(c, hipMemcpyAsync(c->seq.p, bases, n, hipMemcpyHostToDevice, c->stream));
+	}
 	*out = (const u8*)c->seq.p;
 	return 0;
 }
@@ -662,6 +665,9 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 		}
 	}
 	for (auto& e : c->chunk_ev) {
+		(void)hipEventDestroy(e);
+	}
+	for (auto& e : c->h2d_ev) {
 		(void)hipEventDestroy(e);
 	}
 	if (c->stream2) {
@@ -1099,7 +1105,16 @@ ntedit_hip_polish_batch(
 	} while (0)
 	const u64 n_words = (n + 63) / 64;
 	const u8* d_seq = nullptr;
-	if ((rc = stage_bases(c, bases, n, on_device, &d_seq))) {
+	// A batch that arrives in host memory crosses PCIe in pieces while the pieces that are already in HBM are
+	// being screened (SURVEY 8d "kernel region": host buffer in, edit records out).  Page-locked buffers
+	// (ntedit_hip_host_alloc, or any hipHostMalloc / registered memory) copy asynchronously at link speed;
+	// pageable ones are staged by the runtime, the overlap is the same.
+	u64 h2d_piece = 128ull << 20;
+	if (const char* e = getenv("NTEDIT_HIP_H2D_PIECE")) { // tests / tuning: bytes per piece (0 = one copy up front)
+		h2d_piece = strtoull(e, nullptr, 10) / SCREEN_TILE * SCREEN_TILE;
+	}
+	const bool h2d_overlap = !on_device && h2d_piece > 0 && n > 2 * h2d_piece;
+	if ((rc = stage_bases(c, bases, n, on_device, &d_seq, !h2d_overlap))) {
 		return bail(rc);
 	}
 	if ((rc = ensure(c, c->bitmap, (n_words + 1) * 8)) || (rc = ensure(c, c->counters, 256)) ||
@@ -1206,13 +1221,53 @@ ntedit_hip_polish_batch(
 
 		// ---- stream A: every chunk's screening, back to back
 		HIP_BAIL(hipEventRecord(c->ev[0], sA));
-		if (!pipelined) {
+		u32 h2d_launches = 0;
+		u32 slog_unused = 0, nsl_unused = 0;
+		if (!pipelined && h2d_overlap && attempt == 0 && !binned_applicable(c, f0, n, &slog_unused, &nsl_unused)) {
+			// piece j+1 is copied (stream B is idle until the screening is done) while piece j is screened;
+			// the tiles of piece j read k-1 bases of piece j+1, so their launch waits for that copy
+			const u64 n_pieces = (n + h2d_piece - 1) / h2d_piece;
+			while (c->h2d_ev.size() < n_pieces) {
+				hipEvent_t e;
+				HIP_BAIL(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+				c->h2d_ev.push_back(e);
+			}
+			HIP_BAIL(hipEventRecord(c->chunk_ev[0], sA));
+			auto copy_piece = [&](u64 j) -> hipError_t {
+				const u64 o = j * h2d_piece, len = o + h2d_piece < n ? h2d_piece : n - o;
+				hipError_t e = hipMemcpyAsync((char*)c->seq.p + o, bases + o, len, hipMemcpyHostToDevice, sB);
+				return e != hipSuccess ? e : hipEventRecord(c->h2d_ev[j], sB);
+			};
+			HIP_BAIL(copy_piece(0));
+			const u64 tiles_per_piece = h2d_piece / SCREEN_TILE;
+			const u64 total_tiles = (n + SCREEN_TILE - 1) / SCREEN_TILE;
+			for (u64 j = 0; j < n_pieces; j++) {
+				if (j + 1 < n_pieces) {
+					HIP_BAIL(copy_piece(j + 1));
+				}
+				HIP_BAIL(hipStreamWaitEvent(sA, c->h2d_ev[j + 1 < n_pieces ? j + 1 : j], 0));
+				const u64 t0 = j * tiles_per_piece;
+				const u64 t1 = j + 1 < n_pieces ? t0 + tiles_per_piece : total_tiles;
+				if ((rc = launch_screen_tiles<false>(c, sA, d_seq, n, f0, d_bitmap, n_words, t0, t1 - t0, 0))) {
+					return bail(rc);
+				}
+				h2d_launches++;
+			}
+			HIP_BAIL(hipEventRecord(c->chunk_ev[1], sA));
+		} else if (!pipelined) {
+			if (h2d_overlap && attempt == 0) {
+				// (the binned pipeline: the batch goes over in one piece; a retry finds it in HBM already)
+				HIP_BAIL(hipMemcpyAsync(c->seq.p, bases, n, hipMemcpyHostToDevice, sA));
+			}
 			HIP_BAIL(hipEventRecord(c->chunk_ev[0], sA));
 			if ((rc = launch_screen<false>(c, d_seq, n, f0, d_bitmap, n_words))) {
 				return bail(rc);
 			}
 			HIP_BAIL(hipEventRecord(c->chunk_ev[1], sA));
 		} else {
+			if (h2d_overlap && attempt == 0) {
+				HIP_BAIL(hipMemcpyAsync(c->seq.p, bases, n, hipMemcpyHostToDevice, sA));
+			}
 			for (size_t j = 0; j < n_ch; j++) {
 				HIP_BAIL(hipEventRecord(c->chunk_ev[2 * j], sA));
 				if ((rc = launch_screen_tiles<false>(
@@ -1545,7 +1600,7 @@ ntedit_hip_polish_batch(
 				ms_screen += t;
 			}
 			r->st.ms_screen = ms_screen;
-			r->st.screen_launches = (uint32_t)n_scr;
+			r->st.screen_launches = h2d_launches ? h2d_launches : (uint32_t)n_scr;
 			r->st.ms_machine = ms_machine;
 			(void)ms_extract;
 			r->st.ms_extract = 0.f;
@@ -1822,6 +1877,24 @@ ntedit_hip_write_tsv_header(const char* tsv_path, uint32_t k, uint32_t jump, int
 	}
 	nte_host::write_tsv_header(tsv, k, jump, counting != 0);
 	return fclose(tsv) == 0 ? 0 : NTEDIT_E_IO;
+}
+
+void*
+ntedit_hip_host_alloc(size_t bytes)
+{
+	void* p = nullptr;
+	if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+		return nullptr;
+	}
+	return p;
+}
+
+void
+ntedit_hip_host_free(void* p)
+{
+	if (p) {
+		(void)hipHostFree(p);
+	}
 }
 
 void

@@ -25,7 +25,7 @@ import numpy as np
 SEG_NO_HEADER, SEG_NO_NEWLINE, SEG_SKIP = 1, 2, 4
 
 CUT_WINDOW = 1 << 16   # a cut is looked for in this many bases behind its nominal position
-MAX_SEG_BASES = 32_000_000
+MAX_SEG_BASES = 16_000_000
 MIN_SEG_BASES = 1_000_000
 
 
@@ -138,11 +138,12 @@ class Piece:
 
 
 def auto_seg_bases(total, world):
-    """pieces of at most a quarter of a rank's share (LPT then balances to a few percent), within
-    [MIN_SEG_BASES, MAX_SEG_BASES]; one rank: no cutting"""
+    """pieces of at most an eighth of a rank's share (greedy LPT then balances the ranks to a few percent), within
+    [MIN_SEG_BASES, MAX_SEG_BASES]; one rank: no cutting.  A cut costs one 64 KB screening call at planning time
+    and ~150 bases of look-ahead halo, i.e. nothing."""
     if world <= 1:
         return 0
-    return int(max(MIN_SEG_BASES, min(MAX_SEG_BASES, -(-total // (4 * world)))))
+    return int(max(MIN_SEG_BASES, min(MAX_SEG_BASES, -(-total // (8 * world)))))
 
 
 def plan_pieces(records, world, min_len, k, halo, screen_fn, seg_bases=None, refine=True):

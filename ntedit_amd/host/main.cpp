@@ -14,6 +14,7 @@
 #include "../../include/ntedit_hip.h"
 #include "fasta.h"
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -58,7 +59,9 @@ static const char USAGE[] = PROGRAM
     "	-q,	maximum k-mer coverage threshold (CBF only) [default=255]\n"
     "	--gpu N,	HIP device index [default=0]\n"
     "	--batch-bases N,	bases per GPU batch [default=1073741824]\n"
-    "	--shard I/N,	polish only every contig whose index mod N == I (multi-GPU sharding)\n"
+    "	--shard I/N,	polish share I of N of the contigs, split by BASES (greedy longest-first over whole contigs, the\n"
+    "			same on every process); writes <prefix>.index.tsv for `python -m ntedit_amd.merge`.\n"
+    "			(`python -m ntedit_amd.run` is the full multi-GPU driver: one filter broadcast, large contigs cut)\n"
     "	--help,		display this message and exit \n"
     "	--version,	output version information and exit\n\n";
 
@@ -143,12 +146,14 @@ struct Batch
 	std::vector<uint64_t> offs;
 	std::vector<uint32_t> lens;
 	std::vector<std::string> names;
+	std::vector<uint64_t> ordinals; // position of the contig among the contigs >= -z of the whole draft
 	void clear()
 	{
 		blob.clear();
 		offs.clear();
 		lens.clear();
 		names.clear();
+		ordinals.clear();
 	}
 };
 
@@ -427,10 +432,56 @@ main(int argc, char** argv)
 		}
 	}
 
+	// --shard I/N: the contigs >= -z are split by bases, greedy longest-first (the partition of
+	// ntedit_amd.dist.shard_contigs): a first pass over the draft collects the lengths
+	std::vector<uint8_t> mine; // by ordinal
+	if (shard_n > 1) {
+		nte_host::FastaReader scan(draft.c_str());
+		if (!scan.ok()) {
+			fprintf(stderr, PROGRAM ": error: `%s': cannot open\n", draft.c_str());
+			exit(EXIT_FAILURE);
+		}
+		std::vector<uint64_t> lens;
+		std::string h, sq;
+		while (scan.next(h, sq)) {
+			const void* z = memchr(sq.data(), 0, sq.size());
+			const size_t len = z ? (size_t)((const char*)z - sq.data()) : sq.size();
+			if (len >= p.min_contig_len) {
+				lens.push_back(len);
+			}
+			sq.clear();
+		}
+		std::vector<uint32_t> order(lens.size());
+		for (size_t i = 0; i < order.size(); i++) {
+			order[i] = (uint32_t)i;
+		}
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lens[a] > lens[b]; });
+		std::vector<uint64_t> load(shard_n, 0);
+		mine.assign(lens.size(), 0);
+		for (uint32_t i : order) {
+			unsigned best = 0;
+			for (unsigned r = 1; r < shard_n; r++) {
+				if (load[r] < load[best]) {
+					best = r;
+				}
+			}
+			load[best] += lens[i];
+			mine[i] = best == shard_i;
+		}
+	}
 	nte_host::FastaReader reader(draft.c_str());
 	if (!reader.ok()) {
 		fprintf(stderr, PROGRAM ": error: `%s': cannot open\n", draft.c_str());
 		exit(EXIT_FAILURE);
+	}
+	FILE* index_f = nullptr;
+	if (shard_n > 1) {
+		index_f = fopen((prefix + ".index.tsv").c_str(), "wb");
+		if (!index_f) {
+			fprintf(stderr, PROGRAM ": error: cannot write `%s.index.tsv'\n", prefix.c_str());
+			exit(EXIT_FAILURE);
+		}
+		fprintf(index_f, "#shard %u/%u\tordinal\tfa_bytes\ttsv_bytes\tvcf_bytes\n", shard_i, shard_n);
 	}
 	if (threads_given) {
 		ntedit_hip_set_host_threads(nthreads); // -t: contigs rendered concurrently
@@ -485,7 +536,7 @@ main(int argc, char** argv)
 			const size_t len = b.blob.size() - before;
 			bool keep = false;
 			if (len >= p.min_contig_len) { // ntedit.cpp:2242
-				keep = shard_n == 1 || (idx % shard_n) == shard_i;
+				keep = shard_n == 1 || (idx < mine.size() && mine[idx]);
 				idx++;
 			}
 			if (!keep) {
@@ -508,11 +559,13 @@ main(int argc, char** argv)
 					nb.offs.push_back(0);
 					nb.lens.push_back((uint32_t)len);
 					nb.names.push_back(hdr);
+					nb.ordinals.push_back(idx - 1);
 					nb.blob.push_back('\n');
 				} else {
 					b.offs.push_back(before);
 					b.lens.push_back((uint32_t)len);
 					b.names.push_back(hdr);
+					b.ordinals.push_back(idx - 1);
 					b.blob.push_back('\n');
 				}
 				total_bases += len;
@@ -532,13 +585,30 @@ main(int argc, char** argv)
 			for (size_t i = 0; i < b.names.size(); i++) {
 				names[i] = b.names[i].c_str();
 			}
-			int rc = ntedit_hip_write_outputs_vcf(w->res, b.blob.data(), b.offs.data(), b.lens.data(), names.data(),
-			                                      (uint32_t)names.size(), fa_path.c_str(), tsv_path.c_str(),
-			                                      vcf_path.c_str(), 1, p.snv, annot);
+			ntedit_hip_write_options wo;
+			memset(&wo, 0, sizeof wo);
+			wo.fa_path = fa_path.c_str();
+			wo.tsv_path = tsv_path.c_str();
+			wo.vcf_path = vcf_path.c_str();
+			wo.append = 1;
+			wo.annot = annot;
+			std::vector<uint64_t> sizes;
+			if (index_f) {
+				sizes.assign(names.size() * 3 + 3, 0);
+				wo.out_sizes = sizes.data();
+			}
+			int rc = ntedit_hip_write_outputs_ex(w->res, b.blob.data(), b.offs.data(), b.lens.data(), names.data(),
+			                                     (uint32_t)names.size(), &wo);
 			if (rc != 0) {
 				fprintf(stderr, PROGRAM ": error: cannot write outputs\n");
 				fflush(nullptr);
 				_exit(EXIT_FAILURE);
+			}
+			if (index_f) {
+				for (size_t i = 0; i < names.size(); i++) {
+					fprintf(index_f, "%llu\t%llu\t%llu\t%llu\n", (unsigned long long)b.ordinals[i], (unsigned long long)sizes[3 * i],
+					        (unsigned long long)sizes[3 * i + 1], (unsigned long long)sizes[3 * i + 2]);
+				}
 			}
 			ntedit_hip_stats st;
 			ntedit_hip_result_stats(w->res, &st);
@@ -578,6 +648,10 @@ main(int argc, char** argv)
 	write_q.push(nullptr);
 	reader_thread.join();
 	writer_thread.join();
+	if (index_f && fclose(index_f) != 0) {
+		fprintf(stderr, PROGRAM ": error: cannot write `%s.index.tsv'\n", prefix.c_str());
+		exit(EXIT_FAILURE);
+	}
 	if (reader.io_error()) {
 		// a corrupt / truncated input must not pass for a (shorter) genome
 		fprintf(stderr, PROGRAM ": error: `%s': %s -- the outputs are incomplete\n", draft.c_str(), reader.io_error_text().c_str());

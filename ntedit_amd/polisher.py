@@ -250,10 +250,11 @@ class Polisher:
                                                    lens.ctypes.data_as(ctypes.c_void_p), len(lens), 1,
                                                    ctypes.byref(res))
         else:
-            rc = self._lib.ntedit_hip_polish_batch(self._h, ctypes.cast(ctypes.c_char_p(blob), ctypes.c_void_p),
-                                                   len(blob), offsets.ctypes.data_as(ctypes.c_void_p),
+            keep, ptr = Result._blob_ptr(blob)  # bytes, bytearray or a numpy array (e.g. a page-locked buffer)
+            rc = self._lib.ntedit_hip_polish_batch(self._h, ptr, len(blob), offsets.ctypes.data_as(ctypes.c_void_p),
                                                    lens.ctypes.data_as(ctypes.c_void_p), len(lens), 0,
                                                    ctypes.byref(res))
+            del keep
         self._check(rc, "polish_batch")
         return Result(self._lib, res, self)
 

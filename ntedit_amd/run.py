@@ -115,7 +115,7 @@ def parse(argv=None):
     ap.add_argument("-t", dest="threads", type=int, default=0, help="host threads rendering the output")
     ap.add_argument("-k", dest="k_ignored", type=int, help="ignored: k comes from the filter")
     ap.add_argument("--seg-bases", type=int, default=None,
-                    help="cut contigs longer than 1.5x this (default: a quarter of a GPU's share, 1-32 Mbp)")
+                    help="cut contigs longer than 1.5x this (default: an eighth of a GPU's share, 1-32 Mbp)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--report", action="store_true")
     return ap.parse_args(argv)

@@ -212,3 +212,38 @@ def test_filter_file_size_not_a_multiple_of_8_gpu(tmp_path, oracle_build):
             pol.load_filter_file(str(tmp_path / "k5.bf"))
     finally:
         pol.close()
+
+
+def test_cli_shards_by_bases_and_merge(tmp_path, oracle_build):
+    """`ntedit --shard I/N`: shares split by BASES (the partition of dist.shard_contigs), one index per shard,
+    `python -m ntedit_amd.merge` gathers them by ordinal; duplicate contig names do not confuse the gather"""
+    from ntedit_amd import dist as ndist
+    from ntedit_amd.merge import merge_cli_shards
+    cli = os.path.join(H.ROOT, "ntedit_amd", "ntedit")
+    rng = np.random.default_rng(33)
+    truth = H.random_genome(rng, 200000)
+    H.write_fasta(str(tmp_path / "truth.fa"), [(b"t", truth)])
+    H.mkbf([str(tmp_path / "truth.fa")], str(tmp_path / "t.bf"), k=25, hashes=3, nbytes=1 << 20)
+    lens = [60000, 900, 30000, 80, 15000, 15000, 2500, 40000, 700, 12000]
+    recs, pos = [], 0
+    for i, L in enumerate(lens):
+        name = b"dup" if i in (1, 4, 8) else b"c%d x" % i  # the same name three times, far apart
+        recs.append((name, H.mutate(rng, truth[pos:pos + L], 4e-3, 5e-4, 5e-4)))
+        pos += L
+    H.write_fasta(str(tmp_path / "draft.fa"), recs, width=80)
+    H.run_oracle(str(tmp_path / "draft.fa"), str(tmp_path / "t.bf"), H.default_params(), str(tmp_path / "o"))
+    n = 3
+    for i in range(n):
+        r = subprocess.run([cli, "-f", str(tmp_path / "draft.fa"), "-r", str(tmp_path / "t.bf"), "-b", str(tmp_path / ("s%d" % i)),
+                            "--shard", "%d/%d" % (i, n), "--batch-bases", "50000"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    # the shares are the LPT partition by bases of the contigs >= -z
+    kept = [len(s) for _, s in H.read_fasta(str(tmp_path / "draft.fa")) if len(s) >= 100]
+    parts = ndist.shard_contigs(kept, n, 0)
+    for i in range(n):
+        idx = [int(l.split()[0]) for l in open(str(tmp_path / ("s%d.index.tsv" % i))) if not l.startswith("#")]
+        assert idx == [int(x) for x in parts[i]]
+    loads = [sum(kept[int(j)] for j in p) for p in parts]
+    assert max(loads) - min(loads) < 0.1 * sum(loads)
+    assert merge_cli_shards(str(tmp_path / "m"), [str(tmp_path / ("s%d" % i)) for i in range(n)]) == len(kept)
+    _same_outputs(str(tmp_path / "o"), str(tmp_path / "m"))

@@ -85,7 +85,7 @@ struct ntedit_hip_ctx
 	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters, deferred;
 	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps, ws_win;
 	DevBuf offs, lens;
-	DevBuf bin_records, bin_totals, bin_bases, bin_work;
+	DevBuf bin_records, bin_bases, bin_work, wc_counts, wc_wbase;
 	u32 cu_count = 256;
 	std::vector<PinBuf> pin_pool;
 	std::mutex pin_mu;
@@ -337,39 +337,16 @@ launch_screen(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d
 	if (!INSERT) {
 		u32 slog = 0, n_slices = 0;
 		if (binned_applicable(c, f, n, &slog, &n_slices)) {
-			double frac = 1.0; // share of the batch that goes through the binned pipeline
-			if (const char* e = getenv("NTEDIT_HIP_HYBRID_FRAC")) {
-				frac = atof(e);
-			}
-			if (frac >= 1.0) {
-				return run_screen_binned(c, d_seq, n, f, d_bitmap, n_words, slog, n_slices);
-			}
-			// hybrid: the direct kernel (bound by the L2-miss path) and the binned pipeline
-			// (bound by record stores + L2 hits) run side by side on two streams
-			u64 split_tile = (u64)((double)blocks * (1.0 - frac));
-			if (split_tile > blocks) {
-				split_tile = blocks;
-			}
-			const u64 split_pos = split_tile * SCREEN_TILE;
-			HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
-			HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
-			int rc = launch_screen_tiles<false>(c, c->stream, d_seq, n, f, d_bitmap, n_words, 0, split_tile, 44 * 1024);
-			if (rc) {
-				return rc;
-			}
-			rc = run_screen_binned(c, d_seq, n, f, d_bitmap, n_words, slog, n_slices, c->stream2, split_pos, n);
-			if (rc) {
-				return rc;
-			}
-			HIP_TRY(c, hipEventRecord(c->ev[5], c->stream2));
-			HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[5], 0));
-			return 0;
+			return run_screen_binned(c, d_seq, n, f, d_bitmap, n_words, slog, n_slices);
 		}
 	}
 	return launch_screen_tiles<INSERT>(c, c->stream, d_seq, n, f, d_bitmap, n_words, 0, blocks, 0);
 }
 
-// ---- L2-partitioned ("binned") screening; see nte_kernels.hip
+// ---- L2-partitioned ("binned") screening; see nte_kernels.hip / nte_bin_wc.inc
+// screen_mode 1 forces the direct gather kernel, 2 the binned pipeline (tests run it on small inputs); 0 picks:
+// the binned pipeline pays when the filter is far larger than the L2s (the direct kernel then runs at the
+// fabric's ~51 G requests/s) and the batch is large enough to fill the persistent partition kernel.
 bool
 binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_log2, u32* n_slices)
 {
@@ -377,93 +354,70 @@ binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_lo
 	if (mode == 1 || f.hash_num == 0 || f.hash_num > 5 || f.counting || c->hp.snv) {
 		return false;
 	}
-	u32 slog = 24;
+	u32 slog = 24; // 2 MiB slices while the filter has at most WC_MAX_SLICES of them, 4 / 8 MiB beyond
 	u64 ns = (f.bits + (1ULL << slog) - 1) >> slog;
-	while (ns > BIN_MAX_SLICES) {
+	while (ns > (u64)WC_MAX_SLICES) {
 		slog++;
 		ns = (f.bits + (1ULL << slog) - 1) >> slog;
 	}
-	if (slog > 25) {
-		return false; // slices beyond 4 MiB would not stay in an XCD's L2
+	if (slog > 26) {
+		return false; // slices beyond 8 MiB do not stay in an XCD's 4 MiB L2 long enough to matter
 	}
 	*slice_log2 = slog;
 	*n_slices = (u32)ns;
-	(void)n;
-	// Measured on MI355X (3 Gbp, 4 GiB filter, h=3, per 1 Gbp chunk): count 2.1 ms, write
-	// 38 ms (scattered 8-byte stores, ~80 G stores/s), L2-resident probe 18 ms (165 G
-	// probes/s) = 58 ms, the same as the direct kernel's 58.6 ms.  The partial-line store
-	// rate cancels the L2 win, so the pipeline is opt-in (screen_mode = 2) until the write
-	// stage is restructured; see DESIGN.md.
-	return mode == 2;
-}
-
-template<int MODE>
-void
-launch_bin(ntedit_hip_ctx* c, hipStream_t stream, const BinArgs& a, u64 blocks)
-{
-	(void)c;
-	dim3 grid((unsigned)blocks), block(SCREEN_TPB);
-	size_t pad = 0;
-	if (MODE == BIN_WRITE) {
-		if (const char* e = getenv("NTEDIT_HIP_BIN_LDS_PAD")) {
-			pad = (size_t)strtoull(e, nullptr, 10);
-		}
+	if (mode == 2) {
+		return true;
 	}
-	const bool pow2 = a.f.mask != 0;
-#define NTE_BIN(H)                                                                               \
-	do {                                                                                         \
-		if (pow2) {                                                                              \
-			hipLaunchKernelGGL((k_bin<MODE, H, true>), grid, block, pad, stream, a);               \
-		} else {                                                                                 \
-			hipLaunchKernelGGL((k_bin<MODE, H, false>), grid, block, pad, stream, a);              \
-		}                                                                                        \
-	} while (0)
-	switch (a.f.hash_num) {
-	case 1:
-		NTE_BIN(1);
-		break;
-	case 2:
-		NTE_BIN(2);
-		break;
-	case 3:
-		NTE_BIN(3);
-		break;
-	case 4:
-		NTE_BIN(4);
-		break;
-	default:
-		NTE_BIN(5);
-		break;
-	}
-#undef NTE_BIN
+	return f.bits >= (1ULL << 30) && n >= (1ULL << 26); // auto: filters >= 128 MiB, batches >= 64 Mbases
 }
 
 template<int H, bool POW2>
 int
-launch_bin_sort_t(ntedit_hip_ctx* c, hipStream_t stream, const BinArgs& a, u64 blocks)
+launch_wc(ntedit_hip_ctx* c, hipStream_t stream, const WcArgs& w, u64 tiles)
 {
 	static bool attr_set = false;
 	if (!attr_set) {
-		HIP_TRY(c, hipFuncSetAttribute(
-		               reinterpret_cast<const void*>(&k_bin_sort<H, POW2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-		               (int)SORT_LDS_BYTES));
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wc_scatter<H, POW2>),
+		                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_LDS_BYTES));
 		attr_set = true;
 	}
-	hipLaunchKernelGGL((k_bin_sort<H, POW2>), dim3((unsigned)blocks), dim3(SORT_TPB), SORT_LDS_BYTES, stream, a);
+	hipLaunchKernelGGL((k_wc_count<H, POW2>), dim3((unsigned)tiles), dim3(SCREEN_TPB), 0, stream, w);
+	hipLaunchKernelGGL(k_wc_scan, dim3(1), dim3(1024), 0, stream, (const u32*)w.counts, w.n_wg, w.b.n_slices, w.wbase,
+	                   (unsigned long long*)c->bin_bases.p);
+	hipLaunchKernelGGL((k_wc_scatter<H, POW2>), dim3(w.n_wg), dim3(WC_TPB), WC_LDS_BYTES, stream, w);
 	return 0;
 }
 
 int
-launch_bin_sort(ntedit_hip_ctx* c, hipStream_t stream, const BinArgs& a, u64 blocks)
+run_wc_partition(ntedit_hip_ctx* c, hipStream_t stream, const BinArgs& a, u64 tiles)
 {
+	WcArgs w;
+	w.b = a;
+	w.n_wg = c->cu_count; // persistent workgroups, one per CU (the rings take nearly all of a CU's LDS)
+	if ((u64)w.n_wg > tiles) {
+		w.n_wg = (u32)tiles;
+	}
+	w.n_tiles = (u32)tiles;
+	int rc;
+	const size_t cells = (size_t)w.n_wg * a.n_slices;
+	if ((rc = ensure(c, c->wc_counts, cells * 4)) || (rc = ensure(c, c->wc_wbase, cells * 4))) {
+		return rc;
+	}
+	w.counts = (u32*)c->wc_counts.p;
+	w.wbase = (u32*)c->wc_wbase.p;
+	HIP_TRY(c, hipMemsetAsync(w.counts, 0, cells * 4, stream));
 	const bool pow2 = a.f.mask != 0;
 	switch (a.f.hash_num) {
 	case 1:
-		return pow2 ? launch_bin_sort_t<1, true>(c, stream, a, blocks) : launch_bin_sort_t<1, false>(c, stream, a, blocks);
+		return pow2 ? launch_wc<1, true>(c, stream, w, tiles) : launch_wc<1, false>(c, stream, w, tiles);
 	case 2:
-		return pow2 ? launch_bin_sort_t<2, true>(c, stream, a, blocks) : launch_bin_sort_t<2, false>(c, stream, a, blocks);
+		return pow2 ? launch_wc<2, true>(c, stream, w, tiles) : launch_wc<2, false>(c, stream, w, tiles);
+	case 3:
+		return pow2 ? launch_wc<3, true>(c, stream, w, tiles) : launch_wc<3, false>(c, stream, w, tiles);
+	case 4:
+		return pow2 ? launch_wc<4, true>(c, stream, w, tiles) : launch_wc<4, false>(c, stream, w, tiles);
 	default:
-		return pow2 ? launch_bin_sort_t<3, true>(c, stream, a, blocks) : launch_bin_sort_t<3, false>(c, stream, a, blocks);
+		return pow2 ? launch_wc<5, true>(c, stream, w, tiles) : launch_wc<5, false>(c, stream, w, tiles);
 	}
 }
 
@@ -476,10 +430,20 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 	if (pos_end > n) {
 		pos_end = n;
 	}
-	// records per chunk stay below 2^32 (LDS keeps 32-bit bases)
+	// chunks: fewer than 2^32 records each (32-bit record indices), at most 2^30 k-mer starts, and a record
+	// buffer that takes no more than a quarter of the HBM that is free right now
 	u64 chunk = ((1ULL << 32) - (1ULL << 22)) / f.hash_num;
 	if (chunk > (1ULL << 30)) {
 		chunk = 1ULL << 30;
+	}
+	if (c->bin_records.cap < chunk * f.hash_num * 8) {
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+			const u64 room = (u64)(free_b + c->bin_records.cap) / 4 / ((u64)f.hash_num * 8);
+			if (room < chunk) {
+				chunk = room;
+			}
+		}
 	}
 	if (const char* e = getenv("NTEDIT_HIP_BIN_CHUNK")) { // test hook: force several chunks
 		const u64 v = strtoull(e, nullptr, 10);
@@ -488,11 +452,13 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		}
 	}
 	chunk = chunk / SCREEN_TILE * SCREEN_TILE;
+	if (chunk == 0) {
+		return fail(c, NTEDIT_E_DEVICE, "not enough device memory for the screening records");
+	}
 	const u64 span = pos_end - pos_begin;
 	const u64 first_chunk = span < chunk ? (span + SCREEN_TILE - 1) / SCREEN_TILE * SCREEN_TILE : chunk;
 	int rc;
 	if ((rc = ensure(c, c->bin_records, first_chunk * f.hash_num * 8)) ||
-	    (rc = ensure(c, c->bin_totals, (size_t)(n_slices + 1) * 8)) ||
 	    (rc = ensure(c, c->bin_bases, (size_t)(n_slices + 1) * 8)) ||
 	    (rc = ensure(c, c->bin_work, (size_t)(n_slices + 1) * 4))) {
 		return rc;
@@ -502,6 +468,7 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		const u64 w0 = pos_begin / 64, w1 = (pos_end + 63) / 64 < n_words ? (pos_end + 63) / 64 : n_words;
 		HIP_TRY(c, hipMemsetAsync(d_bitmap + w0, 0, (w1 - w0) * 8, stream));
 	}
+	const bool timing = getenv("NTEDIT_HIP_BIN_TIMING") != nullptr; // experiments: per-stage HIP-event times
 	for (u64 begin = pos_begin; begin < pos_end; begin += chunk) {
 		const u64 end = begin + chunk < pos_end ? begin + chunk : pos_end;
 		const u64 blocks = (end - begin + SCREEN_TILE - 1) / SCREEN_TILE;
@@ -515,31 +482,37 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		a.tabs = c->d_tab;
 		a.n_slices = n_slices;
 		a.slice_log2 = slog;
-		a.totals = (unsigned long long*)c->bin_totals.p;
 		a.records = (u64*)c->bin_records.p;
-		HIP_TRY(c, hipMemsetAsync(c->bin_totals.p, 0, (size_t)(n_slices + 1) * 8, stream));
 		HIP_TRY(c, hipMemsetAsync(c->bin_work.p, 0, (size_t)(n_slices + 1) * 4, stream));
-		launch_bin<BIN_COUNT>(c, stream, a, blocks);
-		hipLaunchKernelGGL(
-		    k_bin_scan, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)c->bin_totals.p, n_slices,
-		    (unsigned long long*)c->bin_bases.p, (unsigned long long*)c->bin_totals.p);
-		if (f.hash_num <= SORT_MAX_H && getenv("NTEDIT_HIP_BIN_SORT")) {
-			// LDS-sorted write stage (full-line stores).  Measured: 56 ms per Gbp vs 38 ms for
-			// the plain scatter -- a 4096-k-mer tile is all the LDS holds, and its 2048 run
-			// reservations per tile (global atomics) plus four waves per CU cost more than the
-			// coalescing wins.  Kept for experiments only.
-			const u64 sblocks = (end - begin + SORT_TILE - 1) / SORT_TILE;
-			rc = launch_bin_sort(c, stream, a, sblocks);
-			if (rc) {
-				return rc;
+		hipEvent_t tev[3] = { nullptr, nullptr, nullptr };
+		if (timing) {
+			for (auto& e : tev) {
+				HIP_TRY(c, hipEventCreate(&e));
 			}
-		} else {
-			launch_bin<BIN_WRITE>(c, stream, a, blocks);
+			HIP_TRY(c, hipEventRecord(tev[0], stream));
+		}
+		if ((rc = run_wc_partition(c, stream, a, blocks))) {
+			return rc;
+		}
+		if (timing) {
+			HIP_TRY(c, hipEventRecord(tev[1], stream));
 		}
 		hipLaunchKernelGGL(
 		    k_bin_probe, dim3(c->cu_count * 8), dim3(PROBE_TPB), 0, stream, f.data, (const u64*)c->bin_records.p,
 		    (const unsigned long long*)c->bin_bases.p, n_slices, slog, (u32*)c->bin_work.p, (u32*)d_bitmap);
 		HIP_TRY(c, hipGetLastError());
+		if (timing) {
+			HIP_TRY(c, hipEventRecord(tev[2], stream));
+			HIP_TRY(c, hipStreamSynchronize(stream));
+			float t_part = 0.f, t_probe = 0.f;
+			(void)hipEventElapsedTime(&t_part, tev[0], tev[1]);
+			(void)hipEventElapsedTime(&t_probe, tev[1], tev[2]);
+			fprintf(stderr, "[ntedit_hip] binned chunk %llu k-mers, %u slices of 2^%u bits: partition %.3f ms, probe %.3f ms\n",
+			        (unsigned long long)(end - begin), n_slices, slog, t_part, t_probe);
+			for (auto& e : tev) {
+				(void)hipEventDestroy(e);
+			}
+		}
 	}
 	return 0;
 }
@@ -648,7 +621,7 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 	}
 	DevBuf* bufs[] = { &c->seq,      &c->bitmap,   &c->block_counts, &c->block_offsets, &c->events,
 		               &c->first_chunk, &c->arena, &c->counters, &c->deferred,     &c->ws_nodes,      &c->ws_ov_pos,
-		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->bin_records, &c->bin_totals, &c->bin_bases, &c->bin_work,       &c->offs,          &c->lens };
+		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->bin_records, &c->bin_bases, &c->bin_work, &c->wc_counts, &c->wc_wbase,       &c->offs,          &c->lens };
 	for (DevBuf* b : bufs) {
 		release(*b);
 	}

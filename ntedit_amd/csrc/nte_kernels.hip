@@ -38,6 +38,53 @@ lds_phys(u32 x)
 	return x + ((x >> 6) << 2);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// global store (s_waitcnt vmcnt(0)); the scatter's stores are write-only streams nobody in the kernel
+// reads back, and waiting a memory round trip per round is what the kernel would otherwise be bound by.
+__device__ __forceinline__ void
+lds_barrier()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// stage one tile of the batch as 4-bit codes in LDS (padded rows, see k_screen)
+__device__ __forceinline__ void
+stage_tile(const u8* __restrict__ seq, u64 n, u64 tile_base, u32 tile_len, u32 k, const u8* s_lut, u8* s_codes, u32 tid, u32 tpb)
+{
+	const u32 n_chunks = (tile_len + k - 1 + 15) / 16;
+	for (u32 c = tid; c < n_chunks; c += tpb) {
+		const u64 g = tile_base + (u64)c * 16;
+		u32 w[4];
+		if (g + 16 <= n) {
+			const uint4 v = *reinterpret_cast<const uint4*>(seq + g);
+			w[0] = v.x;
+			w[1] = v.y;
+			w[2] = v.z;
+			w[3] = v.w;
+		} else {
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				u32 x = 0;
+#pragma unroll
+				for (int b = 0; b < 4; b++) {
+					const u64 gg = g + q * 4 + b;
+					const u32 ch = gg < n ? seq[gg] : (u32)'\n';
+					x |= ch << (8 * b);
+				}
+				w[q] = x;
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const u32 x = w[q];
+			const u32 codes = (u32)s_lut[x & 0xFF] | ((u32)s_lut[(x >> 8) & 0xFF] << 8) |
+			                  ((u32)s_lut[(x >> 16) & 0xFF] << 16) | ((u32)s_lut[x >> 24] << 24);
+			*reinterpret_cast<u32*>(&s_codes[lds_phys(c * 16 + q * 4)]) = codes;
+		}
+	}
+}
+
+
 template<int H, bool POW2, bool INSERT>
 __global__ __launch_bounds__(SCREEN_TPB) void
 k_screen(
@@ -70,38 +117,7 @@ k_screen(
 
 	const u64 tile_base = (first_tile + blockIdx.x) * SCREEN_TILE;
 	const u32 k = p.k;
-	// ---- stage the tile: 16-byte chunks, translated to codes
-	const u32 n_chunks = (SCREEN_TILE + k - 1 + 15) / 16;
-	for (u32 c = tid; c < n_chunks; c += SCREEN_TPB) {
-		const u64 g = tile_base + (u64)c * 16;
-		u32 w[4];
-		if (g + 16 <= n) {
-			const uint4 v = *reinterpret_cast<const uint4*>(seq + g);
-			w[0] = v.x;
-			w[1] = v.y;
-			w[2] = v.z;
-			w[3] = v.w;
-		} else {
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				u32 x = 0;
-#pragma unroll
-				for (int b = 0; b < 4; b++) {
-					const u64 gg = g + q * 4 + b;
-					const u32 ch = gg < n ? seq[gg] : (u32)'\n';
-					x |= ch << (8 * b);
-				}
-				w[q] = x;
-			}
-		}
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			const u32 x = w[q];
-			const u32 codes = (u32)s_lut[x & 0xFF] | ((u32)s_lut[(x >> 8) & 0xFF] << 8) |
-			                  ((u32)s_lut[(x >> 16) & 0xFF] << 16) | ((u32)s_lut[x >> 24] << 24);
-			*reinterpret_cast<u32*>(&s_codes[lds_phys(c * 16 + q * 4)]) = codes;
-		}
-	}
+	stage_tile(seq, n, tile_base, SCREEN_TILE, k, s_lut, s_codes, tid, SCREEN_TPB);
 	__syncthreads();
 
 	// ---- per-thread stream of 64 k-mer starts
@@ -221,25 +237,17 @@ k_screen(
 }
 
 // ------------------------------------------------------- binned screening
-// The direct kernel above is bound by the L2-miss path: every 1-byte probe of a
-// multi-GiB filter costs one 64-byte fabric request (~51 G requests/s measured, the same
-// as a pure random-gather micro-benchmark), while gathers that HIT in an XCD's 4 MiB L2
-// run at ~270 G/s.  The binned pipeline makes the probes L2-resident:
-//   k_bin<COUNT>   hash every k-mer of a chunk, histogram its h probes by filter slice
-//   k_bin_scan     exclusive scan of the slice totals -> slice base offsets
-//   k_bin<WRITE>   hash again, append {position, offset-in-slice} records slice by slice
-//   k_bin_probe    every XCD walks "its" slices (slice % 8 == XCD) one after the other:
-//                  the slice's 2 MiB of filter stay in that XCD's L2 while its records
-//                  stream by; a zero bit ORs the k-mer's bit into the absent bitmap
+// The direct kernel above is bound by the L2-miss path: every 1-byte probe of a multi-GiB filter costs one
+// 64-byte fabric request (~51 G requests/s measured, the same as a pure random-gather micro-benchmark),
+// while gathers that HIT in an XCD's 4 MiB L2 run at up to ~270 G/s.  The binned pipeline makes the probes
+// L2-resident by partitioning them by filter slice first:
+//   k_wc_count / k_wc_scan / k_wc_scatter   (nte_bin_wc.inc) write-combining partition of the h probes of
+//                  every k-mer into {position, offset-in-slice} records, slice by slice
+//   k_bin_probe    every XCD walks "its" slices (slice % 8 == XCD) one after the other: the slice's 2-4 MiB
+//                  of filter stay in that XCD's L2 while its records stream by; a zero bit ORs the k-mer's
+//                  bit into the absent bitmap
 // Records are 8 bytes: (global k-mer position << slice_log2) | bit offset in slice.
-constexpr int BIN_MAX_SLICES = 2048; // LDS histogram capacity; slices are >= 2 MiB (2^24 bits)
-
-enum
-{
-	BIN_COUNT = 0,
-	BIN_WRITE = 1
-};
-
+// Measured (MI355X, 3 Gbp, 4 GiB filter, h = 3): 116-121 ms against 176 ms for the direct kernel.
 struct BinArgs
 {
 	const u8* seq;
@@ -251,340 +259,8 @@ struct BinArgs
 	const u64* tabs;
 	u32 n_slices;
 	u32 slice_log2;  // log2(bits per slice)
-	unsigned long long* totals;  // [n_slices] COUNT: += ; WRITE: running cursors (start = base)
 	u64* records;    // < 2^32 records per chunk
 };
-
-template<int MODE, int H, bool POW2>
-__global__ __launch_bounds__(SCREEN_TPB) void
-k_bin(BinArgs a)
-{
-	__shared__ u64 s_tab[TAB_WORDS];
-	__shared__ u8 s_lut[256];
-	__shared__ __attribute__((aligned(16))) u8 s_codes[SCREEN_LDS_BYTES];
-	__shared__ u32 s_hist[BIN_MAX_SLICES];
-	__shared__ u32 s_base[MODE == BIN_WRITE ? BIN_MAX_SLICES : 1];
-	extern __shared__ u8 s_pad[]; // occupancy limiter (tuning): bounds the open-line working set
-	if (MODE == BIN_WRITE && a.n == 0) {
-		s_pad[threadIdx.x] = 0;
-	}
-
-	const u32 tid = threadIdx.x;
-	if (tid < TAB_WORDS) {
-		s_tab[tid] = a.tabs[tid];
-	}
-	s_lut[tid] = char_code((u8)tid);
-	for (u32 b = tid; b < a.n_slices; b += SCREEN_TPB) {
-		s_hist[b] = 0;
-	}
-	__syncthreads();
-
-	const u64 tile_base = a.chunk_begin + (u64)blockIdx.x * SCREEN_TILE;
-	const u32 k = a.p.k;
-	const u32 n_chunks = (SCREEN_TILE + k - 1 + 15) / 16;
-	for (u32 c = tid; c < n_chunks; c += SCREEN_TPB) {
-		const u64 g = tile_base + (u64)c * 16;
-		u32 w[4];
-		if (g + 16 <= a.n) {
-			const uint4 v = *reinterpret_cast<const uint4*>(a.seq + g);
-			w[0] = v.x;
-			w[1] = v.y;
-			w[2] = v.z;
-			w[3] = v.w;
-		} else {
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				u32 x = 0;
-#pragma unroll
-				for (int b = 0; b < 4; b++) {
-					const u64 gg = g + q * 4 + b;
-					const u32 ch = gg < a.n ? a.seq[gg] : (u32)'\n';
-					x |= ch << (8 * b);
-				}
-				w[q] = x;
-			}
-		}
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			const u32 x = w[q];
-			const u32 codes = (u32)s_lut[x & 0xFF] | ((u32)s_lut[(x >> 8) & 0xFF] << 8) |
-			                  ((u32)s_lut[(x >> 16) & 0xFF] << 16) | ((u32)s_lut[x >> 24] << 24);
-			*reinterpret_cast<u32*>(&s_codes[lds_phys(c * 16 + q * 4)]) = codes;
-		}
-	}
-	__syncthreads();
-
-	const u32 x0 = tid * SCREEN_L;
-	const u32 ksh = (k & 3) * 8;
-	const u32 slog = a.slice_log2;
-	const u64 slice_mask = (1ULL << slog) - 1;
-
-	// the rolling pass; `emit` = false: histogram only, true: place records
-	auto pass = [&](bool emit) {
-		HashState hs = { 0, 0 };
-		u32 good = 0;
-		for (u32 i = 0; i < k; i++) {
-			const u8 in = s_codes[lds_phys(x0 + i)];
-			hash_roll(hs, s_tab, CODE_BAD, in);
-			good = in == CODE_BAD ? 0 : good + 1;
-		}
-		u32 in_lo = *reinterpret_cast<const u32*>(&s_codes[lds_phys((x0 + k) & ~3u)]);
-		for (u32 j0 = 0; j0 < SCREEN_L; j0 += 4) {
-			const u32 outw = *reinterpret_cast<const u32*>(&s_codes[lds_phys(x0 + j0)]);
-			const u32 in_hi = *reinterpret_cast<const u32*>(&s_codes[lds_phys(((x0 + j0 + k) & ~3u) + 4)]);
-			const u32 inw = ksh ? ((in_lo >> ksh) | (in_hi << (32 - ksh))) : in_lo;
-			in_lo = in_hi;
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const u64 pos = tile_base + x0 + j0 + u;
-				if (good >= k && pos < a.chunk_end) {
-					const u64 base = hs.fh + hs.rh;
-#pragma unroll
-					for (int i = 0; i < H; i++) {
-						const u64 hv = hash_extend(base, a.p, i);
-						const u64 slot = POW2 ? (hv & a.f.mask) : filter_slot(a.f, hv);
-						const u32 sl = (u32)(slot >> slog);
-						const u32 r = atomicAdd(&s_hist[sl], 1u);
-						if (MODE == BIN_WRITE && emit) {
-							a.records[(u64)s_base[sl] + r] = (pos << slog) | (slot & slice_mask);
-						}
-					}
-				}
-				const u8 out = (outw >> (8 * u)) & 0xFF;
-				const u8 in = (inw >> (8 * u)) & 0xFF;
-				hash_roll(hs, s_tab, out, in);
-				good = in == CODE_BAD ? 0 : good + 1;
-			}
-		}
-	};
-
-	pass(false);
-	__syncthreads();
-	for (u32 b = tid; b < a.n_slices; b += SCREEN_TPB) {
-		const u32 cnt = s_hist[b];
-		if (MODE == BIN_COUNT) {
-			if (cnt) {
-				atomicAdd(&a.totals[b], (unsigned long long)cnt);
-			}
-		} else {
-			s_base[b] = cnt ? (u32)atomicAdd(&a.totals[b], (unsigned long long)cnt) : 0;
-			s_hist[b] = 0;
-		}
-	}
-	if (MODE == BIN_WRITE) {
-		__syncthreads();
-		pass(true);
-	}
-}
-
-// k_bin_sort: the WRITE stage with full-line stores.  k_bin<WRITE> scatters every 8-byte
-// record on its own (one partial-line store per probe, ~80 G stores/s).  Here a workgroup
-// sorts the records of its tile by slice in LDS first (counting sort with LDS atomics), then
-// copies the sorted array out linearly: consecutive lanes hold consecutive records of the same
-// (tile, slice) run, i.e. consecutive global addresses, so the stores coalesce into lines.
-constexpr int SORT_TPB = 256;
-constexpr int SORT_L = 16; // k-mer starts per thread
-constexpr int SORT_TILE = SORT_TPB * SORT_L;
-constexpr int SORT_MAX_H = 3;
-constexpr int SORT_CODE_BYTES = ((SORT_TILE + SCREEN_MAXK + 63) / 64) * 68 + 16;
-// dynamic LDS: records | cnt | loff | gbase | codes
-constexpr size_t SORT_LDS_BYTES = (size_t)SORT_TILE * SORT_MAX_H * 8 + (size_t)BIN_MAX_SLICES * 4 * 2 +
-                                  (size_t)(BIN_MAX_SLICES + 1) * 4 + SORT_CODE_BYTES;
-
-template<int H, bool POW2>
-__global__ __launch_bounds__(SORT_TPB) void
-k_bin_sort(BinArgs a)
-{
-	__shared__ u64 s_tab[TAB_WORDS];
-	__shared__ u8 s_lut[256];
-	__shared__ u32 s_scan[SORT_TPB];
-	extern __shared__ __attribute__((aligned(16))) u8 s_dyn[];
-	u64* s_rec = reinterpret_cast<u64*>(s_dyn);
-	u32* s_cnt = reinterpret_cast<u32*>(s_dyn + (size_t)SORT_TILE * SORT_MAX_H * 8);
-	u32* s_gbase = s_cnt + BIN_MAX_SLICES;
-	u32* s_loff = s_gbase + BIN_MAX_SLICES; // n_slices + 1 entries
-	u8* s_codes = reinterpret_cast<u8*>(s_loff + BIN_MAX_SLICES + 1);
-
-	const u32 tid = threadIdx.x;
-	if (tid < TAB_WORDS) {
-		s_tab[tid] = a.tabs[tid];
-	}
-	s_lut[tid] = char_code((u8)tid);
-	for (u32 b = tid; b < a.n_slices; b += SORT_TPB) {
-		s_cnt[b] = 0;
-	}
-	__syncthreads();
-
-	const u64 tile_base = a.chunk_begin + (u64)blockIdx.x * SORT_TILE;
-	const u32 k = a.p.k;
-	const u32 n_chunks = (SORT_TILE + k - 1 + 15) / 16;
-	for (u32 c = tid; c < n_chunks; c += SORT_TPB) {
-		const u64 g = tile_base + (u64)c * 16;
-		u32 w[4];
-		if (g + 16 <= a.n) {
-			const uint4 v = *reinterpret_cast<const uint4*>(a.seq + g);
-			w[0] = v.x;
-			w[1] = v.y;
-			w[2] = v.z;
-			w[3] = v.w;
-		} else {
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				u32 x = 0;
-#pragma unroll
-				for (int b = 0; b < 4; b++) {
-					const u64 gg = g + q * 4 + b;
-					const u32 ch = gg < a.n ? a.seq[gg] : (u32)'\n';
-					x |= ch << (8 * b);
-				}
-				w[q] = x;
-			}
-		}
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			const u32 x = w[q];
-			const u32 codes = (u32)s_lut[x & 0xFF] | ((u32)s_lut[(x >> 8) & 0xFF] << 8) |
-			                  ((u32)s_lut[(x >> 16) & 0xFF] << 16) | ((u32)s_lut[x >> 24] << 24);
-			*reinterpret_cast<u32*>(&s_codes[lds_phys(c * 16 + q * 4)]) = codes;
-		}
-	}
-	__syncthreads();
-
-	const u32 x0 = tid * SORT_L;
-	const u32 ksh = (k & 3) * 8;
-	const u32 slog = a.slice_log2;
-	const u64 slice_mask = (1ULL << slog) - 1;
-
-	auto pass = [&](bool place) {
-		HashState hs = { 0, 0 };
-		u32 good = 0;
-		for (u32 i = 0; i < k; i++) {
-			const u8 in = s_codes[lds_phys(x0 + i)];
-			hash_roll(hs, s_tab, CODE_BAD, in);
-			good = in == CODE_BAD ? 0 : good + 1;
-		}
-		u32 in_lo = *reinterpret_cast<const u32*>(&s_codes[lds_phys((x0 + k) & ~3u)]);
-		for (u32 j0 = 0; j0 < SORT_L; j0 += 4) {
-			const u32 outw = *reinterpret_cast<const u32*>(&s_codes[lds_phys(x0 + j0)]);
-			const u32 in_hi = *reinterpret_cast<const u32*>(&s_codes[lds_phys(((x0 + j0 + k) & ~3u) + 4)]);
-			const u32 inw = ksh ? ((in_lo >> ksh) | (in_hi << (32 - ksh))) : in_lo;
-			in_lo = in_hi;
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const u64 pos = tile_base + x0 + j0 + u;
-				if (good >= k && pos < a.chunk_end) {
-					const u64 base = hs.fh + hs.rh;
-#pragma unroll
-					for (int i = 0; i < H; i++) {
-						const u64 hv = hash_extend(base, a.p, i);
-						const u64 slot = POW2 ? (hv & a.f.mask) : filter_slot(a.f, hv);
-						const u32 sl = (u32)(slot >> slog);
-						const u32 r = atomicAdd(&s_cnt[sl], 1u);
-						if (place) {
-							s_rec[s_loff[sl] + r] = (pos << slog) | (slot & slice_mask);
-						}
-					}
-				}
-				const u8 out = (outw >> (8 * u)) & 0xFF;
-				const u8 in = (inw >> (8 * u)) & 0xFF;
-				hash_roll(hs, s_tab, out, in);
-				good = in == CODE_BAD ? 0 : good + 1;
-			}
-		}
-	};
-
-	pass(false);
-	__syncthreads();
-	// exclusive prefix of the slice counts -> local offsets; reserve the global runs
-	{
-		const u32 per = (a.n_slices + SORT_TPB - 1) / SORT_TPB;
-		const u32 b0 = tid * per;
-		u32 sum = 0;
-		for (u32 b = b0; b < b0 + per && b < a.n_slices; b++) {
-			sum += s_cnt[b];
-		}
-		s_scan[tid] = sum;
-		__syncthreads();
-		for (int off = 1; off < SORT_TPB; off <<= 1) {
-			u32 t = 0;
-			if ((int)tid >= off) {
-				t = s_scan[tid - off];
-			}
-			__syncthreads();
-			s_scan[tid] += t;
-			__syncthreads();
-		}
-		u32 run = s_scan[tid] - sum;
-		for (u32 b = b0; b < b0 + per && b < a.n_slices; b++) {
-			const u32 cnt = s_cnt[b];
-			s_loff[b] = run;
-			run += cnt;
-			s_gbase[b] = cnt ? (u32)atomicAdd(&a.totals[b], (unsigned long long)cnt) : 0;
-			s_cnt[b] = 0;
-		}
-		if (tid == SORT_TPB - 1) {
-			s_loff[a.n_slices] = s_scan[SORT_TPB - 1];
-		}
-	}
-	__syncthreads();
-	pass(true);
-	__syncthreads();
-	// linear copy-out; the slice of sorted record i = last b with loff[b] <= i
-	const u32 n_rec = s_loff[a.n_slices];
-	for (u32 i = tid; i < n_rec; i += SORT_TPB) {
-		u32 lo = 0, hi = a.n_slices;
-		while (hi - lo > 1) {
-			const u32 mid = (lo + hi) >> 1;
-			if (s_loff[mid] <= i) {
-				lo = mid;
-			} else {
-				hi = mid;
-			}
-		}
-		a.records[(u64)s_gbase[lo] + (i - s_loff[lo])] = s_rec[i];
-	}
-}
-
-// exclusive scan of the slice totals (single workgroup); cursors[b] = bases[b]
-__global__ __launch_bounds__(1024) void
-k_bin_scan(const unsigned long long* totals, u32 n_slices, unsigned long long* bases, unsigned long long* cursors)
-{
-	__shared__ unsigned long long s_part[1024];
-	__shared__ unsigned long long s_carry;
-	if (threadIdx.x == 0) {
-		s_carry = 0;
-	}
-	__syncthreads();
-	for (u32 base = 0; base < n_slices; base += 1024) {
-		const u32 i = base + threadIdx.x;
-		const unsigned long long v = i < n_slices ? totals[i] : 0;
-		s_part[threadIdx.x] = v;
-		__syncthreads();
-		for (int off = 1; off < 1024; off <<= 1) {
-			unsigned long long t = 0;
-			if ((int)threadIdx.x >= off) {
-				t = s_part[threadIdx.x - off];
-			}
-			__syncthreads();
-			s_part[threadIdx.x] += t;
-			__syncthreads();
-		}
-		const unsigned long long incl = s_part[threadIdx.x];
-		const unsigned long long carry = s_carry;
-		if (i < n_slices) {
-			bases[i] = carry + incl - v;
-			cursors[i] = carry + incl - v;
-		}
-		__syncthreads();
-		if (threadIdx.x == 1023) {
-			s_carry = carry + incl;
-		}
-		__syncthreads();
-	}
-	if (threadIdx.x == 0) {
-		bases[n_slices] = s_carry;
-	}
-}
 
 // Every workgroup asks the hardware which XCD it runs on (HW_REG_XCC_ID) and serves the
 // slices {x, x+8, x+16, ...} of that XCD, pulling 1024-record pieces of the current slice
@@ -592,7 +268,9 @@ k_bin_scan(const unsigned long long* totals, u32 n_slices, unsigned long long* b
 // slice, whose 2 MiB of filter is fetched into that XCD's L2 once and then hit by all of
 // its records.  Placement only affects speed, never the result.
 constexpr int PROBE_TPB = 256;
-constexpr int PROBE_PIECE = PROBE_TPB * 4;
+constexpr int PROBE_SUB = 4;   // records per thread per step (independent gathers in flight)
+constexpr int PROBE_STEPS = 8; // steps per piece; the records of step s+1 are loaded while step s gathers
+constexpr int PROBE_PIECE = PROBE_TPB * PROBE_SUB * PROBE_STEPS;
 
 __device__ __forceinline__ u32
 xcc_id()
@@ -611,45 +289,65 @@ k_bin_probe(
     u32* __restrict__ work, // [n_slices] zeroed piece counters
     u32* __restrict__ absent32)
 {
-	__shared__ u32 s_piece;
+	__shared__ u32 s_piece[2];
 	const u64 off_mask = (1ULL << slog) - 1;
 	const u32 xcd = xcc_id();
+	const u32 tid = threadIdx.x;
 	for (u32 sl = xcd; sl < n_slices; sl += 8) {
 		const u64 lo = bases[sl], hi = bases[sl + 1];
 		const u8* fs = filter + ((u64)sl << (slog - 3));
-		while (true) {
+		// the piece counter is read one piece ahead: its round trip hides behind the current piece
+		if (tid == 0) {
+			s_piece[0] = atomicAdd(&work[sl], 1u);
+		}
+		for (u32 it = 0;; it++) {
 			__syncthreads();
-			if (threadIdx.x == 0) {
-				s_piece = atomicAdd(&work[sl], 1u);
-			}
-			__syncthreads();
-			const u64 i0 = lo + (u64)s_piece * PROBE_PIECE;
+			const u64 i0 = lo + (u64)s_piece[it & 1] * PROBE_PIECE;
 			if (i0 >= hi) {
 				break;
 			}
-			u64 rec[4];
-			u8 byte[4];
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const u64 i = i0 + (u64)q * PROBE_TPB + threadIdx.x;
-				rec[q] = i < hi ? records[i] : ~0ULL;
+			if (tid == 0) {
+				s_piece[(it + 1) & 1] = atomicAdd(&work[sl], 1u);
 			}
+			u64 cur[PROBE_SUB];
 #pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const u32 off = (u32)(rec[q] & off_mask);
-				byte[q] = rec[q] != ~0ULL ? fs[off >> 3] : (u8)0xFF;
+			for (int q = 0; q < PROBE_SUB; q++) {
+				const u64 i = i0 + (u64)q * PROBE_TPB + tid;
+				cur[q] = i < hi ? __builtin_nontemporal_load(records + i) : ~0ULL;
 			}
+#pragma unroll 2
+			for (int st = 0; st < PROBE_STEPS; st++) {
+				u64 nxt[PROBE_SUB];
 #pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const u32 off = (u32)(rec[q] & off_mask);
-				if (!((byte[q] >> (off & 7)) & 1)) {
-					const u64 pos = rec[q] >> slog;
-					atomicOr(&absent32[pos >> 5], 1u << (pos & 31));
+				for (int q = 0; q < PROBE_SUB; q++) {
+					const u64 i = i0 + (u64)((st + 1) * PROBE_SUB + q) * PROBE_TPB + tid;
+					nxt[q] = (st + 1 < PROBE_STEPS && i < hi) ? __builtin_nontemporal_load(records + i) : ~0ULL;
+				}
+				u8 byte[PROBE_SUB];
+#pragma unroll
+				for (int q = 0; q < PROBE_SUB; q++) {
+					const u32 off = (u32)(cur[q] & off_mask);
+					byte[q] = cur[q] != ~0ULL ? fs[off >> 3] : (u8)0xFF;
+				}
+#pragma unroll
+				for (int q = 0; q < PROBE_SUB; q++) {
+					const u32 off = (u32)(cur[q] & off_mask);
+					if (!((byte[q] >> (off & 7)) & 1)) {
+						const u64 pos = cur[q] >> slog;
+						atomicOr(&absent32[pos >> 5], 1u << (pos & 31));
+					}
+				}
+#pragma unroll
+				for (int q = 0; q < PROBE_SUB; q++) {
+					cur[q] = nxt[q];
 				}
 			}
 		}
+		__syncthreads();
 	}
 }
+
+#include "nte_bin_wc.inc"
 
 // ------------------------------------------------------------ event starts
 // bits of word w whose position lies in [pos_lo, pos_hi)

@@ -137,13 +137,16 @@ def test_demo_ecoli(tmp_path, oracle_build):
     assert st.bases > 4_600_000
 
 
-@pytest.mark.parametrize("ci", [0, 1, 3, 16, 23, 24, 25])
+@pytest.mark.parametrize("ci", [0, 1, 3, 16, 23, 24, 25, 100, 101])
 def test_binned_screen_matches_oracle(tmp_path, ci, oracle_build, monkeypatch):
-    """the L2-partitioned screening pipeline (count / scan / write / probe) gives the same bitmap
-    as the oracle, incl. several chunks, non-power-of-two filters and 1..6 hashes"""
+    """the L2-partitioned screening pipeline (write-combining partition of the probes by filter slice: count /
+    scan / scatter, then the L2-resident probe) gives the same bitmap as the oracle, incl. several chunks,
+    non-power-of-two filters, 1..6 hashes (6: falls back to the direct kernel) and a one-slice filter whose ring
+    overflows all the time (the direct-store path).  Cases 100/101: filters of many slices."""
     import ntedit_amd
     monkeypatch.setenv("NTEDIT_HIP_BIN_CHUNK", str(3 * 16384))
-    case_kw, _ = H.PARITY_CONFIGS[ci]
+    case_kw, _ = H.PARITY_CONFIGS[ci] if ci < 100 else (dict(bfbytes=(1 << 27) if ci == 100 else 100000007 * 8, n=150000,
+                                                           flavor="N rep"), {})
     case = H.make_case(str(tmp_path), 4000 + ci, **case_kw)
     bf = H.load_bf(case["bf"])
     blob, offs, lens, names = H.pack_batch(H.read_fasta(case["draft"]))

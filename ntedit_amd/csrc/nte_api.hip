@@ -86,6 +86,7 @@ struct ntedit_hip_ctx
 	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps, ws_win;
 	DevBuf offs, lens;
 	DevBuf bin_records, bin_bases, bin_work, wc_counts, wc_wbase;
+	DevBuf ev_cover, ev_before, ev_flags, ev_list, ev_bmax; // event rounds
 	u32 cu_count = 256;
 	std::vector<PinBuf> pin_pool;
 	std::mutex pin_mu;
@@ -621,7 +622,7 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 	}
 	DevBuf* bufs[] = { &c->seq,      &c->bitmap,   &c->block_counts, &c->block_offsets, &c->events,
 		               &c->first_chunk, &c->arena, &c->counters, &c->deferred,     &c->ws_nodes,      &c->ws_ov_pos,
-		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->bin_records, &c->bin_bases, &c->bin_work, &c->wc_counts, &c->wc_wbase,       &c->offs,          &c->lens };
+		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->bin_records, &c->bin_bases, &c->bin_work, &c->wc_counts, &c->wc_wbase, &c->ev_cover, &c->ev_before, &c->ev_flags, &c->ev_list, &c->ev_bmax,       &c->offs,          &c->lens };
 	for (DevBuf* b : bufs) {
 		release(*b);
 	}
@@ -1399,58 +1400,159 @@ ntedit_hip_polish_batch(
 			if (n_ch != 1) {
 				a.p.event_budget = 0; // (parked events are re-run per batch: single-chunk batches only)
 			}
-			HIP_BAIL(hipMemsetAsync(d_ndef, 0, 4, sB));
-			HIP_BAIL(hipEventRecord(c->ev[3], sB));
-			// pass 1: every event, indel sweeps postponed
-			HIP_BAIL(hipMemsetAsync(a.work_counter, 0, 4, sB));
-			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] pass1 launch: blocks %llu events %llu\n", (unsigned long long)blocks, (unsigned long long)a.n_events); }
-			launch_k_machine_thread((unsigned)blocks, dyn_lds, sB, a);
-			HIP_BAIL(hipGetLastError());
-			u32 h_tail[4] = { 0, 0, 0, 0 };
-			HIP_BAIL(hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
-			HIP_BAIL(hipEventRecord(c->ev[5], sB));
-			HIP_BAIL(hipStreamSynchronize(sB));
-			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] pass1 done: deferred %u status %u\n", h_tail[3], h_tail[2]); }
-			const u32 n_def = h_tail[3];
-			deferred_total += n_def;
-			status = h_tail[2];
-			if (n_def > 0 && status == 0 && n_ch == 1 && !getenv("NTEDIT_HIP_NO_EARLY_COPY")) {
-				// everything pass 1 wrote is final (pass 2 only appends chunks): start moving it
-				// to the host on the other stream while pass 2 runs
-				early_chunks = h_tail[0] < arena_chunks ? h_tail[0] : arena_chunks;
-				const u64 room = early_chunks + (u64)n_def * 3 + 4096;
-				if ((rc = pin_take(c, room * CHUNK_ITEMS * sizeof(Item) + 16, &early))) {
+			// ---- rounds (see "event rounds" in nte_kernels.hip): primaries, then the secondaries their
+			// primary's run does not overtake, then -- practically never -- whatever a verification rejects.
+			// Pipeline chunks and SNV mode run everything in one round.
+			const bool rounds = n_ch == 1 && !c->dp.snv && n_ev < 0xFFFFFF00ull && !getenv("NTEDIT_HIP_NO_ROUNDS");
+			u32* d_list = nullptr;
+			u32* d_list_n = (u32*)((char*)c->counters.p + 64);
+			u64* d_before = nullptr;
+			u64* d_bmax = nullptr;
+			const u32 n32 = (u32)n_ev;
+			const u32 sel_blocks = (n32 + EVR_TPB - 1) / EVR_TPB;
+			const u32 pm_blocks = (n32 + 1023) / 1024;
+			a.ev_cover = nullptr;
+			a.ev_flags = nullptr;
+			if (rounds) {
+				if ((rc = ensure(c, c->ev_cover, n_ev * 8)) || (rc = ensure(c, c->ev_before, n_ev * 8)) ||
+				    (rc = ensure(c, c->ev_flags, n_ev)) || (rc = ensure(c, c->ev_list, n_ev * 4)) ||
+				    (rc = ensure(c, c->ev_bmax, (size_t)pm_blocks * 8 + 8))) {
 					return bail(rc);
 				}
-				if (early_chunks) {
-					HIP_BAIL(hipMemcpyAsync(early.p, c->arena.p, early_chunks * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sA));
+				a.ev_cover = (u64*)c->ev_cover.p;
+				a.ev_flags = (u8*)c->ev_flags.p;
+				d_list = (u32*)c->ev_list.p;
+				d_before = (u64*)c->ev_before.p;
+				d_bmax = (u64*)c->ev_bmax.p;
+				HIP_BAIL(hipMemsetAsync(a.ev_cover, 0, n_ev * 8, sB));
+			}
+			HIP_BAIL(hipEventRecord(c->ev[3], sB));
+			u32 n_def = 0;
+			float p2_ms = 0.f;
+			// one round = pass 1 over a list of events (indel sweeps postponed), pass 2 over the postponed ones
+			auto run_round = [&](const u32* list, u32 count, bool first_round) -> int {
+				if (count == 0) {
+					return 0;
+				}
+				MachineArgs ra = a;
+				ra.ev_list = list;
+				ra.n_events = count;
+				HIP_TRY(c, hipMemsetAsync(d_ndef, 0, 4, sB));
+				HIP_TRY(c, hipMemsetAsync(ra.work_counter, 0, 4, sB));
+				const u64 want = ((u64)count + MACHINE_TPB - 1) / MACHINE_TPB;
+				launch_k_machine_thread((unsigned)(want < blocks ? want : blocks), dyn_lds, sB, ra);
+				HIP_TRY(c, hipGetLastError());
+				u32 h_tail[4] = { 0, 0, 0, 0 };
+				HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+				HIP_TRY(c, hipEventRecord(c->ev[5], sB));
+				HIP_TRY(c, hipStreamSynchronize(sB));
+				const u32 nd = h_tail[3];
+				n_def += nd;
+				status = h_tail[2];
+				if (first_round && nd > 0 && status == 0 && n_ch == 1 && !getenv("NTEDIT_HIP_NO_EARLY_COPY")) {
+					// everything pass 1 wrote is final (later launches only append chunks): start moving it
+					// to the host on the other stream while the sweeps run
+					early_chunks = h_tail[0] < arena_chunks ? h_tail[0] : arena_chunks;
+					const u64 room = early_chunks + (u64)nd * 3 + 4096;
+					int prc = pin_take(c, room * CHUNK_ITEMS * sizeof(Item) + 16, &early);
+					if (prc) {
+						return prc;
+					}
+					if (early_chunks) {
+						HIP_TRY(c, hipMemcpyAsync(early.p, c->arena.p, early_chunks * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sA));
+					}
+				}
+				if (nd > 0 && status == 0) {
+					MachineArgs a2 = ra;
+					a2.ev_list = nullptr;
+					if (const char* dbg = getenv("NTEDIT_HIP_PASS2_DEBUG")) {
+						a2.p.debug_stop = (u32)atoi(dbg); // timing ablations; results are NOT valid
+					}
+					hipEvent_t e0 = c->ev[5];
+					launch_wave_pass(a2, (const u32*)c->deferred.p, nd);
+					HIP_TRY(c, hipGetLastError());
+					HIP_TRY(c, hipEventRecord(c->ev[2], sB));
+					HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+					HIP_TRY(c, hipStreamSynchronize(sB));
+					status = h_tail[2];
+					float t = 0.f;
+					(void)hipEventElapsedTime(&t, e0, c->ev[2]);
+					p2_ms += t;
+				}
+				return 0;
+			};
+			u32 n_A = n32, n_B = 0, n_C = 0;
+			if (!rounds) {
+				if ((rc = run_round(nullptr, n32, true))) {
+					return bail(rc);
+				}
+			} else {
+				const u32 gap = c->dp.k + 16;
+				auto list_count = [&](u32* out) -> int {
+					HIP_TRY(c, hipMemcpyAsync(out, d_list_n, 4, hipMemcpyDeviceToHost, sB));
+					HIP_TRY(c, hipStreamSynchronize(sB));
+					return 0;
+				};
+				auto prefix_max = [&]() {
+					hipLaunchKernelGGL(k_ev_prefix_max_1, dim3(pm_blocks), dim3(1024), 0, sB, (const u64*)a.ev_cover, n32, d_before, d_bmax);
+					hipLaunchKernelGGL(k_ev_prefix_max_2, dim3(pm_blocks), dim3(1024), 0, sB, n32, d_before, (const u64*)d_bmax);
+				};
+				HIP_BAIL(hipMemsetAsync(d_list_n, 0, 4, sB));
+				hipLaunchKernelGGL(k_ev_primaries, dim3(sel_blocks), dim3(EVR_TPB), 0, sB, (const u64*)d_events, n32, gap, a.ev_flags, d_list, d_list_n);
+				if ((rc = list_count(&n_A)) || (rc = run_round(d_list, n_A, true))) {
+					return bail(rc);
+				}
+				if (status == 0 && n_A < n32) {
+					prefix_max();
+					HIP_BAIL(hipMemsetAsync(d_list_n, 0, 4, sB));
+					hipLaunchKernelGGL(k_ev_select<0>, dim3(sel_blocks), dim3(EVR_TPB), 0, sB, (const u64*)d_events, n32,
+					                   (const u64*)a.ev_cover, (const u64*)d_before, a.ev_flags, d_first, d_list, d_list_n);
+					if ((rc = list_count(&n_B)) || (rc = run_round(d_list, n_B, false))) {
+						return bail(rc);
+					}
+					if (status == 0) {
+						prefix_max();
+						HIP_BAIL(hipMemsetAsync(d_list_n, 0, 4, sB));
+						hipLaunchKernelGGL(k_ev_select<1>, dim3(sel_blocks), dim3(EVR_TPB), 0, sB, (const u64*)d_events, n32,
+						                   (const u64*)a.ev_cover, (const u64*)d_before, a.ev_flags, d_first, d_list, d_list_n);
+						if ((rc = list_count(&n_C))) {
+							return bail(rc);
+						}
+						for (int guard = 0; n_C && status == 0 && guard < 64; guard++) {
+							// (a run of round B reached a primary: its secondaries cannot be taken for overtaken)
+							if ((rc = run_round(d_list, n_C, false))) {
+								return bail(rc);
+							}
+							prefix_max();
+							HIP_BAIL(hipMemsetAsync(d_list_n, 0, 4, sB));
+							hipLaunchKernelGGL(k_ev_select<1>, dim3(sel_blocks), dim3(EVR_TPB), 0, sB, (const u64*)d_events, n32,
+							                   (const u64*)a.ev_cover, (const u64*)d_before, a.ev_flags, d_first, d_list, d_list_n);
+							if ((rc = list_count(&n_C))) {
+								return bail(rc);
+							}
+						}
+					}
 				}
 			}
-			if (n_def > 0 && status == 0) {
-				// pass 2: one wavefront per event that needs an indel sweep
-				MachineArgs a2 = a;
-				if (const char* dbg = getenv("NTEDIT_HIP_PASS2_DEBUG")) {
-					a2.p.debug_stop = (u32)atoi(dbg); // timing ablations; results are NOT valid
-				}
-				launch_wave_pass(a2, (const u32*)c->deferred.p, n_def);
-				HIP_BAIL(hipGetLastError());
-			}
+			HIP_BAIL(hipGetLastError());
+			u32 h_tail[4] = { 0, 0, 0, 0 };
 			keep_a = a;
 			HIP_BAIL(hipEventRecord(c->ev[4], sB));
 			HIP_BAIL(hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
 			HIP_BAIL(hipStreamSynchronize(sB));
 			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] pass2 done: status %u\n", h_tail[2]); }
 			status = h_tail[2];
-			float p1 = 0.f, p2 = 0.f;
-			(void)hipEventElapsedTime(&p1, c->ev[3], c->ev[5]);
-			(void)hipEventElapsedTime(&p2, c->ev[5], c->ev[4]);
-			ms_machine += p1 + p2;
+			deferred_total += n_def;
+			float p_all = 0.f;
+			(void)hipEventElapsedTime(&p_all, c->ev[3], c->ev[4]);
+			ms_machine += p_all;
 			if (getenv("NTEDIT_HIP_DEBUG")) {
 				fprintf(
 				    stderr,
-				    "[ntedit_hip] chunk %zu/%zu contigs %u-%u events %llu deferred %u pass1 %.3f ms pass2 %.3f ms arena %u "
-				    "status %u window %u\n",
-				    j + 1, n_ch, ch.c0, ch.c1, (unsigned long long)n_ev, n_def, p1, p2, h_tail[0], status, c->dp.node_window);
+				    "[ntedit_hip] chunk %zu/%zu contigs %u-%u events %llu (round A %u, B %u, C %u; %u skipped as overtaken) sweeps %u "
+				    "machine %.3f ms (sweep launches %.3f ms) arena %u status %u window %u\n",
+				    j + 1, n_ch, ch.c0, ch.c1, (unsigned long long)n_ev, n_A, n_B, n_C, n32 - n_A - n_B - (rounds ? 0 : 0), n_def,
+				    p_all, p2_ms, h_tail[0], status, c->dp.node_window);
 			}
 			if (getenv("NTEDIT_HIP_DEBUG")) {
 				unsigned long long pr[16];

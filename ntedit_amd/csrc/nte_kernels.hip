@@ -268,9 +268,7 @@ struct BinArgs
 // slice, whose 2 MiB of filter is fetched into that XCD's L2 once and then hit by all of
 // its records.  Placement only affects speed, never the result.
 constexpr int PROBE_TPB = 256;
-constexpr int PROBE_SUB = 4;   // records per thread per step (independent gathers in flight)
-constexpr int PROBE_STEPS = 8; // steps per piece; the records of step s+1 are loaded while step s gathers
-constexpr int PROBE_PIECE = PROBE_TPB * PROBE_SUB * PROBE_STEPS;
+constexpr int PROBE_PIECE = PROBE_TPB * 4;
 
 __device__ __forceinline__ u32
 xcc_id()
@@ -289,61 +287,43 @@ k_bin_probe(
     u32* __restrict__ work, // [n_slices] zeroed piece counters
     u32* __restrict__ absent32)
 {
-	__shared__ u32 s_piece[2];
+	__shared__ u32 s_piece;
 	const u64 off_mask = (1ULL << slog) - 1;
 	const u32 xcd = xcc_id();
-	const u32 tid = threadIdx.x;
 	for (u32 sl = xcd; sl < n_slices; sl += 8) {
 		const u64 lo = bases[sl], hi = bases[sl + 1];
 		const u8* fs = filter + ((u64)sl << (slog - 3));
-		// the piece counter is read one piece ahead: its round trip hides behind the current piece
-		if (tid == 0) {
-			s_piece[0] = atomicAdd(&work[sl], 1u);
-		}
-		for (u32 it = 0;; it++) {
+		while (true) {
 			__syncthreads();
-			const u64 i0 = lo + (u64)s_piece[it & 1] * PROBE_PIECE;
+			if (threadIdx.x == 0) {
+				s_piece = atomicAdd(&work[sl], 1u);
+			}
+			__syncthreads();
+			const u64 i0 = lo + (u64)s_piece * PROBE_PIECE;
 			if (i0 >= hi) {
 				break;
 			}
-			if (tid == 0) {
-				s_piece[(it + 1) & 1] = atomicAdd(&work[sl], 1u);
+			u64 rec[4];
+			u8 byte[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const u64 i = i0 + (u64)q * PROBE_TPB + threadIdx.x;
+				rec[q] = i < hi ? records[i] : ~0ULL;
 			}
-			u64 cur[PROBE_SUB];
 #pragma unroll
-			for (int q = 0; q < PROBE_SUB; q++) {
-				const u64 i = i0 + (u64)q * PROBE_TPB + tid;
-				cur[q] = i < hi ? __builtin_nontemporal_load(records + i) : ~0ULL;
+			for (int q = 0; q < 4; q++) {
+				const u32 off = (u32)(rec[q] & off_mask);
+				byte[q] = rec[q] != ~0ULL ? fs[off >> 3] : (u8)0xFF;
 			}
-#pragma unroll 2
-			for (int st = 0; st < PROBE_STEPS; st++) {
-				u64 nxt[PROBE_SUB];
 #pragma unroll
-				for (int q = 0; q < PROBE_SUB; q++) {
-					const u64 i = i0 + (u64)((st + 1) * PROBE_SUB + q) * PROBE_TPB + tid;
-					nxt[q] = (st + 1 < PROBE_STEPS && i < hi) ? __builtin_nontemporal_load(records + i) : ~0ULL;
-				}
-				u8 byte[PROBE_SUB];
-#pragma unroll
-				for (int q = 0; q < PROBE_SUB; q++) {
-					const u32 off = (u32)(cur[q] & off_mask);
-					byte[q] = cur[q] != ~0ULL ? fs[off >> 3] : (u8)0xFF;
-				}
-#pragma unroll
-				for (int q = 0; q < PROBE_SUB; q++) {
-					const u32 off = (u32)(cur[q] & off_mask);
-					if (!((byte[q] >> (off & 7)) & 1)) {
-						const u64 pos = cur[q] >> slog;
-						atomicOr(&absent32[pos >> 5], 1u << (pos & 31));
-					}
-				}
-#pragma unroll
-				for (int q = 0; q < PROBE_SUB; q++) {
-					cur[q] = nxt[q];
+			for (int q = 0; q < 4; q++) {
+				const u32 off = (u32)(rec[q] & off_mask);
+				if (!((byte[q] >> (off & 7)) & 1)) {
+					const u64 pos = rec[q] >> slog;
+					atomicOr(&absent32[pos >> 5], 1u << (pos & 31));
 				}
 			}
 		}
-		__syncthreads();
 	}
 }
 
@@ -512,6 +492,164 @@ k_write_starts(
 		events[o++] = w * 64 + b;
 		m &= m - 1;
 	}
+}
+
+// ------------------------------------------------------------ event rounds
+// Events are speculative: one that starts inside an earlier event's serial run is discarded by the
+// serial-order filter.  With a Bloom filter's false positives an absent run is often broken into two or three
+// pieces, every piece starts an event, and all but the first of them are, as a rule, overtaken by the first one's
+// run -- after having cost as much machine time as the useful events together (measured: 26 % of the events, 42 %
+// of the machine work).  The launch driver therefore runs the events in rounds:
+//   round A   PRIMARY events: no other event starts within `gap` positions in front of them
+//   select    a SECONDARY event is skipped iff it starts inside the run of its cluster's primary P
+//             (events[i] < cover[P], P ran to its end) and P itself is certainly applied: no event that has run
+//             so far reaches P (max cover of all earlier run events <= start of P; k_ev_prefix_max)
+//   round B   the secondaries that are not skipped
+//   verify    the "certainly applied" test again with round B's runs; any violation -> the skipped events run too
+// A skipped event is exactly one the serial order discards (cover only grows along a contig), so the records
+// the host gets are the same set of APPLIED events as before; first_chunk = NONE32 makes it skip the others.
+constexpr u8 EVC_PRIMARY = 0x20, EVC_SKIPPED = 0x40, EVC_RAN = 0x80; // (+ EV_UNFINISHED = 0x10 from the machine)
+constexpr int EVR_TPB = 256;
+
+__device__ __forceinline__ void
+wave_append(u32* list, u32* count, bool pred, u32 value)
+{
+	const u64 m = __ballot(pred);
+	if (m) {
+		const u32 lane = __lane_id();
+		const u32 leader = (u32)__ffsll((long long)m) - 1;
+		u32 base = 0;
+		if (lane == leader) {
+			base = atomicAdd(count, (u32)__popcll(m));
+		}
+		base = __shfl(base, leader, 64);
+		if (pred) {
+			list[base + (u32)__popcll(m & ((1ULL << lane) - 1))] = value;
+		}
+	}
+}
+
+__global__ __launch_bounds__(EVR_TPB) void
+k_ev_primaries(const u64* __restrict__ events, u32 n, u32 gap, u8* __restrict__ flags, u32* __restrict__ list, u32* __restrict__ count)
+{
+	const u32 i = blockIdx.x * EVR_TPB + threadIdx.x;
+	bool prim = false;
+	if (i < n) {
+		prim = i == 0 || events[i] - events[i - 1] > gap;
+		flags[i] = prim ? EVC_PRIMARY : 0;
+	}
+	wave_append(list, count, prim, i);
+}
+
+// exclusive prefix maximum of cover[] (0 for events that have not run): stage 1, per block
+__global__ __launch_bounds__(1024) void
+k_ev_prefix_max_1(const u64* __restrict__ cover, u32 n, u64* __restrict__ before, u64* __restrict__ block_max)
+{
+	__shared__ u64 s[1024];
+	const u32 i = blockIdx.x * 1024 + threadIdx.x;
+	const u64 v = i < n ? cover[i] : 0;
+	s[threadIdx.x] = v;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1) {
+		u64 t = 0;
+		if ((int)threadIdx.x >= off) {
+			t = s[threadIdx.x - off];
+		}
+		__syncthreads();
+		if (t > s[threadIdx.x]) {
+			s[threadIdx.x] = t;
+		}
+		__syncthreads();
+	}
+	if (i < n) {
+		before[i] = threadIdx.x ? s[threadIdx.x - 1] : 0; // exclusive, within the block
+	}
+	if (threadIdx.x == 1023) {
+		block_max[blockIdx.x] = s[1023];
+	}
+}
+
+// stage 2: fold in the maxima of all earlier blocks
+__global__ __launch_bounds__(1024) void
+k_ev_prefix_max_2(u32 n, u64* __restrict__ before, const u64* __restrict__ block_max)
+{
+	__shared__ u64 s_red[16];
+	u64 carry = 0;
+	for (u32 b = threadIdx.x; b < blockIdx.x; b += 1024) {
+		const u64 v = block_max[b];
+		carry = v > carry ? v : carry;
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		const u64 o = __shfl_down(carry, off, 64);
+		carry = o > carry ? o : carry;
+	}
+	if ((threadIdx.x & 63) == 0) {
+		s_red[threadIdx.x >> 6] = carry;
+	}
+	__syncthreads();
+	carry = 0;
+	for (int w = 0; w < 16; w++) {
+		carry = s_red[w] > carry ? s_red[w] : carry;
+	}
+	const u32 i = blockIdx.x * 1024 + threadIdx.x;
+	if (i < n && carry > before[i]) {
+		before[i] = carry;
+	}
+}
+
+// the primary of event i's cluster (walking back over at most 64 secondaries), or NONE32
+__device__ __forceinline__ u32
+cluster_primary(const u8* __restrict__ flags, u32 i)
+{
+	for (u32 step = 1; step <= 64 && step <= i; step++) {
+		if (flags[i - step] & EVC_PRIMARY) {
+			return i - step;
+		}
+	}
+	return NONE32;
+}
+
+// MODE 0: decide the secondaries (skip or append to `list`).  MODE 1: verify the skipped ones (count violations in
+// *count and append them to `list`).
+template<int MODE>
+__global__ __launch_bounds__(EVR_TPB) void
+k_ev_select(
+    const u64* __restrict__ events,
+    u32 n,
+    const u64* __restrict__ cover,
+    const u64* __restrict__ before,
+    u8* __restrict__ flags,
+    u32* __restrict__ first_chunk,
+    u32* __restrict__ list,
+    u32* __restrict__ count)
+{
+	const u32 i = blockIdx.x * EVR_TPB + threadIdx.x;
+	bool take = false;
+	if (i < n) {
+		const u8 f = flags[i];
+		const bool candidate = MODE == 0 ? !(f & EVC_PRIMARY) : (f & EVC_SKIPPED) != 0;
+		if (candidate) {
+			const u32 P = cluster_primary(flags, i);
+			bool covered = false;
+			if (P != NONE32) {
+				const u8 pf = flags[P];
+				const bool p_done = (pf & EVC_RAN) && !(pf & EV_UNFINISHED);
+				covered = p_done && before[P] <= events[P] && events[i] < cover[P];
+			}
+			if (MODE == 0) {
+				if (covered) {
+					flags[i] = (u8)(f | EVC_SKIPPED);
+					first_chunk[i] = NONE32;
+				} else {
+					take = true;
+				}
+			} else if (!covered) {
+				flags[i] = (u8)(f & ~EVC_SKIPPED);
+				take = true;
+			}
+		}
+	}
+	wave_append(list, count, take, i);
 }
 
 // (k_machine lives in its own translation units, nte_machine_thread.hip / nte_machine_wave.hip:

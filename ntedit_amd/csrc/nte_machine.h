@@ -2162,6 +2162,32 @@ struct Machine
 					break;
 				}
 			}
+			// Behind a substitution the next k-1 k-mers hold the new base; they were probed together
+			// (look-ahead) and, as a rule, are all there: the reference rolls through them one position
+			// at a time doing nothing.  With the rope untouched (one position node, cursors k-1 apart)
+			// that stretch of the walk is a pure function of the draft window, so it is taken in one
+			// stride: land on the last position that is looked-ahead, present and still dirty.
+			if (!missing && !rope_touched && la_i < la_n && last_sub_pos >= (int64_t)h_seq_i) {
+				u32 J = 0;
+				while (la_i + J + 1 < la_n && ((la_mask >> (la_i + J + 1)) & 1) &&
+				       (int64_t)h_seq_i + J + 1 <= last_sub_pos && (u64)h_seq_i + J + 1 + p.k - 1 < e.len) {
+					J++;
+				}
+				if (p.event_budget) {
+					const u32 room = steps < p.event_budget ? p.event_budget - steps : 0;
+					J = J < room ? J : room;
+				}
+				if (J) {
+					for (u32 q = 0; q < J; q++) {
+						hash_roll(hs, e.tab, win_o(la_i + q), win_i(la_i + q));
+					}
+					h_seq_i += J;
+					t_seq_i += J;
+					la_i += J;
+					steps += J;
+					char_in = seq_at(t_seq_i);
+				}
+			}
 			// advance; skip over k-mers containing a non-accepted base (ntedit.cpp:2119-2138)
 			bool ended = false;
 			int64_t target = -1;

@@ -46,6 +46,11 @@ struct MachineArgs
 	u32* deferred;
 	u32* n_deferred;
 	u32* n_unfinished; // events parked by the budget (p.event_budget) in this launch
+	// per event, written for every event a launch runs to its end: where its serial run ended, as a byte
+	// position of the batch (contig offset + cover_end), and its flags (EV_UNFINISHED: the end is unknown).
+	// The launch driver uses them to skip events that start inside an earlier event's run (nullptr: not kept)
+	u64* ev_cover;
+	u8* ev_flags;
 	// dynamic work distribution: every worker (thread / wavefront) takes the next event from this
 	// counter (zeroed before the launch) -- event costs are heavy-tailed, a static split leaves most of
 	// the chip waiting for the unluckiest worker

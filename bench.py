@@ -359,6 +359,9 @@ def main():
     screen_ms = [ms for _, ms in stats]
     machine_ms = [st.ms_machine for st, _ in stats if st is not None]
     last = stats[-1][0] if stats else None
+    binned = bool(last is not None and last.screen_binned)
+    probe_ms = [st.ms_probe for st, _ in stats if st is not None]
+    part_ms = [st.ms_partition for st, _ in stats if st is not None]
 
     shard_bases = [my_bases]
     if world > 1:
@@ -381,11 +384,21 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_bases * args.steps / elapsed / 1e6
-        # k_screen runs `launches[0]` times per step (pipeline chunks); the per-launch figures are what
-        # rocprofv3's kernel stats average over
+        # Screening = the dominant part of a step.  Direct path: ONE kernel (k_screen), algorithmic bytes per k-mer
+        # start = h filter bytes + 1 draft byte + 1/8 bitmap byte.  Binned path: four kernels per record
+        # chunk; the dominant one is k_bin_probe, whose share of those bytes is the h filter bytes + the bitmap
+        # byte/8 (the draft byte is read by the partition kernels); the per-launch figures are what rocprofv3's
+        # kernel stats average over.  `pipeline` prices the whole screening at the full 4.125 B per k-mer start.
         step_screen = sum(screen_ms) / len(screen_ms)
-        avg_screen = step_screen / launches[0]
-        algo_bytes = (args.hashes + 1 + 0.125) * my_bytes / launches[0]  # h filter B + 1 draft B + 1/8 bitmap B
+        if binned:
+            step_probe = sum(probe_ms) / len(probe_ms)
+            avg_screen = step_probe / launches[0]
+            algo_bytes = (args.hashes + 0.125) * my_bytes / launches[0]
+            dom_kernel = "k_bin_probe"
+        else:
+            avg_screen = step_screen / launches[0]
+            algo_bytes = (args.hashes + 1 + 0.125) * my_bytes / launches[0]  # h filter B + 1 draft B + 1/8 bitmap B
+            dom_kernel = "k_screen"
         achieved = algo_bytes / (avg_screen * 1e-3) / 1e9
         out = {
             "metric": "polished Mbases/s",
@@ -415,7 +428,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_screen",
+                "kernel": dom_kernel,
                 "achieved": round(achieved, 2),
                 "peak": 8000.0,
                 "unit": "GB/s",
@@ -425,26 +438,39 @@ def main():
                 "avg_launch_ms": round(avg_screen, 3),
                 "launches_per_step": launches[0],
                 "probes_per_s": round(args.hashes * my_bytes / (step_screen * 1e-3), 0),
+                "pipeline": {
+                    "kernels": ["k_wc_count", "k_wc_scan", "k_wc_scatter", "k_bin_probe"] if binned else ["k_screen"],
+                    "ms_per_step": round(step_screen, 3),
+                    "algorithmic_bytes_per_step": int((args.hashes + 1 + 0.125) * my_bytes),
+                    "achieved": round((args.hashes + 1 + 0.125) * my_bytes / (step_screen * 1e-3) / 1e9, 2),
+                    "frac": round((args.hashes + 1 + 0.125) * my_bytes / (step_screen * 1e-3) / 1e9 / 8000.0, 5),
+                    "partition_ms": round(sum(part_ms) / len(part_ms), 3) if binned else None,
+                    "probe_ms": round(sum(probe_ms) / len(probe_ms), 3) if binned else None,
+                },
             },
             "setup_s": round(t_setup, 1),
         }
         if weak is not None:
             out["weak"] = weak
-        # HBM traffic of the same launch from the committed PMC run (bench.py cannot collect
-        # counters itself); only quoted when it was taken on this exact workload
+        # HBM traffic of the dominant kernel's launches from the committed PMC run (bench.py cannot collect counters
+        # itself); only quoted when it was taken on this exact workload
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
-            if int(tr["workload_bytes"]) == int(my_bytes) and launches[0] == 1 and args.hashes == 3 and \
-                    str(tr.get("kernel", "k_screen")).startswith(out["roofline"]["kernel"]):
-                out["roofline"]["traffic"] = int(tr["fetch_bytes_per_launch"] + tr["write_bytes_per_launch"])
+            kk = [k for k in tr["kernels"] if k.split("<")[0] == dom_kernel]
+            if int(tr["workload_bytes"]) == int(my_bytes) and args.hashes == 3 and kk and \
+                    int(tr["kernels"][kk[0]]["launches"]) % launches[0] == 0:
+                e = tr["kernels"][kk[0]]
+                out["roofline"]["traffic"] = int(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"])
                 out["roofline"]["traffic_source"] = tr["source"]
+                out["roofline"]["l2_hit_rate"] = round(e["tcc_hit_rate"], 4) if e.get("tcc_hit_rate") is not None else None
         except Exception:
             pass
         if last is not None:
             out["phases_ms"] = {"screen_launches_sum": round(step_screen, 3),
                                 "machine_launches_sum": round(sum(machine_ms) / len(machine_ms), 3),
                                 "other": round(ms_per_step - step_screen - sum(machine_ms) / len(machine_ms), 3)}
-            out["events"] = {"absent_kmers": int(last.absent_kmers), "event_threads": int(last.events),
+            out["events"] = {"absent_kmers": int(last.absent_kmers), "event_starts": int(last.events),
+                             "skipped_as_overtaken": int(last.events_skipped),
                              "deferred_to_sweep_pass": int(last.events_deferred)}
         if not args.no_gather:
             try:

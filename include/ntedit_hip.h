@@ -169,7 +169,12 @@ typedef struct ntedit_hip_stats
 	float ms_extract;        /* (folded into ms_machine's stream; 0)          */
 	float ms_machine;        /* event machine launches (sum); overlaps screening when pipelined */
 	float ms_total;          /* first kernel start -> edit records in host memory */
-	uint32_t screen_launches; /* k_screen launches of this batch (pipeline chunks) */
+	uint32_t screen_launches; /* launches of the dominant screening kernel in this batch: k_bin_probe (binned
+	                             screening, one per record chunk) or k_screen (direct; pipeline chunks / H2D pieces) */
+	uint32_t screen_binned;   /* 1: binned pipeline (k_wc_count, k_wc_scan, k_wc_scatter, k_bin_probe), 0: k_screen */
+	float ms_partition;       /* binned: HIP-event time of the partition kernels (count + scan + scatter), sum */
+	float ms_probe;           /* binned: HIP-event time of the k_bin_probe launches, sum */
+	uint32_t events_skipped;  /* events not run because they start inside their cluster primary's run */
 	uint32_t reserved;
 } ntedit_hip_stats;
 int ntedit_hip_result_stats(const ntedit_hip_result* r, ntedit_hip_stats* s);

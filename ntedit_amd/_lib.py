@@ -53,6 +53,10 @@ class Stats(ctypes.Structure):
         ("ms_machine", ctypes.c_float),
         ("ms_total", ctypes.c_float),
         ("screen_launches", ctypes.c_uint32),
+        ("screen_binned", ctypes.c_uint32),
+        ("ms_partition", ctypes.c_float),
+        ("ms_probe", ctypes.c_float),
+        ("events_skipped", ctypes.c_uint32),
         ("reserved", ctypes.c_uint32),
     ]
 

@@ -73,6 +73,8 @@ struct ntedit_hip_ctx
 	hipStream_t stream2 = nullptr; // event extraction + machine of the chunk pipeline
 	std::vector<hipEvent_t> chunk_ev; // 2 per chunk on `stream` (screen begin / end)
 	std::vector<hipEvent_t> h2d_ev;   // one per host-to-device piece of a host-resident batch
+	std::vector<hipEvent_t> bin_ev;   // 3 per record chunk of the binned screening (start, partitioned, probed)
+	u32 bin_chunks_last = 0;          // chunks of the last binned screening (0: the direct kernel ran)
 	DevFilter filt[2];
 	ntedit_hip_params hp;
 	DevParams dp;
@@ -341,6 +343,9 @@ launch_screen(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d
 			return run_screen_binned(c, d_seq, n, f, d_bitmap, n_words, slog, n_slices);
 		}
 	}
+	if (!INSERT) {
+		c->bin_chunks_last = 0;
+	}
 	return launch_screen_tiles<INSERT>(c, c->stream, d_seq, n, f, d_bitmap, n_words, 0, blocks, 0);
 }
 
@@ -469,8 +474,9 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		const u64 w0 = pos_begin / 64, w1 = (pos_end + 63) / 64 < n_words ? (pos_end + 63) / 64 : n_words;
 		HIP_TRY(c, hipMemsetAsync(d_bitmap + w0, 0, (w1 - w0) * 8, stream));
 	}
-	const bool timing = getenv("NTEDIT_HIP_BIN_TIMING") != nullptr; // experiments: per-stage HIP-event times
-	for (u64 begin = pos_begin; begin < pos_end; begin += chunk) {
+	const bool timing = getenv("NTEDIT_HIP_BIN_TIMING") != nullptr; // experiments: per-stage times on stderr
+	u32 chunk_no = 0;
+	for (u64 begin = pos_begin; begin < pos_end; begin += chunk, chunk_no++) {
 		const u64 end = begin + chunk < pos_end ? begin + chunk : pos_end;
 		const u64 blocks = (end - begin + SCREEN_TILE - 1) / SCREEN_TILE;
 		BinArgs a;
@@ -484,37 +490,33 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		a.n_slices = n_slices;
 		a.slice_log2 = slog;
 		a.records = (u64*)c->bin_records.p;
-		HIP_TRY(c, hipMemsetAsync(c->bin_work.p, 0, (size_t)(n_slices + 1) * 4, stream));
-		hipEvent_t tev[3] = { nullptr, nullptr, nullptr };
-		if (timing) {
-			for (auto& e : tev) {
-				HIP_TRY(c, hipEventCreate(&e));
-			}
-			HIP_TRY(c, hipEventRecord(tev[0], stream));
+		while (c->bin_ev.size() < 3 * (size_t)(chunk_no + 1)) {
+			hipEvent_t e;
+			HIP_TRY(c, hipEventCreate(&e));
+			c->bin_ev.push_back(e);
 		}
+		hipEvent_t* tev = &c->bin_ev[3 * (size_t)chunk_no];
+		HIP_TRY(c, hipMemsetAsync(c->bin_work.p, 0, (size_t)(n_slices + 1) * 4, stream));
+		HIP_TRY(c, hipEventRecord(tev[0], stream));
 		if ((rc = run_wc_partition(c, stream, a, blocks))) {
 			return rc;
 		}
-		if (timing) {
-			HIP_TRY(c, hipEventRecord(tev[1], stream));
-		}
+		HIP_TRY(c, hipEventRecord(tev[1], stream));
 		hipLaunchKernelGGL(
 		    k_bin_probe, dim3(c->cu_count * 8), dim3(PROBE_TPB), 0, stream, f.data, (const u64*)c->bin_records.p,
 		    (const unsigned long long*)c->bin_bases.p, n_slices, slog, (u32*)c->bin_work.p, (u32*)d_bitmap);
 		HIP_TRY(c, hipGetLastError());
+		HIP_TRY(c, hipEventRecord(tev[2], stream));
 		if (timing) {
-			HIP_TRY(c, hipEventRecord(tev[2], stream));
 			HIP_TRY(c, hipStreamSynchronize(stream));
 			float t_part = 0.f, t_probe = 0.f;
 			(void)hipEventElapsedTime(&t_part, tev[0], tev[1]);
 			(void)hipEventElapsedTime(&t_probe, tev[1], tev[2]);
 			fprintf(stderr, "[ntedit_hip] binned chunk %llu k-mers, %u slices of 2^%u bits: partition %.3f ms, probe %.3f ms\n",
 			        (unsigned long long)(end - begin), n_slices, slog, t_part, t_probe);
-			for (auto& e : tev) {
-				(void)hipEventDestroy(e);
-			}
 		}
 	}
+	c->bin_chunks_last = chunk_no;
 	return 0;
 }
 
@@ -642,6 +644,9 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 		(void)hipEventDestroy(e);
 	}
 	for (auto& e : c->h2d_ev) {
+		(void)hipEventDestroy(e);
+	}
+	for (auto& e : c->bin_ev) {
 		(void)hipEventDestroy(e);
 	}
 	if (c->stream2) {
@@ -1255,7 +1260,7 @@ ntedit_hip_polish_batch(
 
 		// ---- stream B: per chunk, as soon as its screening is done
 		u64 ev_total = 0;      // events of the chunks processed so far
-		u64 absent_total = 0, deferred_total = 0;
+		u64 absent_total = 0, deferred_total = 0, skipped_total = 0;
 		u32 status = 0;
 		float ms_extract = 0.f, ms_machine = 0.f;
 		bool first_b = true;
@@ -1543,6 +1548,7 @@ ntedit_hip_polish_batch(
 			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] pass2 done: status %u\n", h_tail[2]); }
 			status = h_tail[2];
 			deferred_total += n_def;
+			skipped_total += rounds ? (u64)n32 - n_A - n_B : 0; // (events round C had to run are few; they stay counted here)
 			float p_all = 0.f;
 			(void)hipEventElapsedTime(&p_all, c->ev[3], c->ev[4]);
 			ms_machine += p_all;
@@ -1676,6 +1682,18 @@ ntedit_hip_polish_batch(
 			}
 			r->st.ms_screen = ms_screen;
 			r->st.screen_launches = h2d_launches ? h2d_launches : (uint32_t)n_scr;
+			if (!pipelined && !h2d_launches && c->bin_chunks_last) {
+				r->st.screen_binned = 1;
+				r->st.screen_launches = c->bin_chunks_last;
+				for (u32 q = 0; q < c->bin_chunks_last; q++) {
+					float tp = 0.f, tq = 0.f;
+					(void)hipEventElapsedTime(&tp, c->bin_ev[3 * q], c->bin_ev[3 * q + 1]);
+					(void)hipEventElapsedTime(&tq, c->bin_ev[3 * q + 1], c->bin_ev[3 * q + 2]);
+					r->st.ms_partition += tp;
+					r->st.ms_probe += tq;
+				}
+			}
+			r->st.events_skipped = (uint32_t)skipped_total;
 			r->st.ms_machine = ms_machine;
 			(void)ms_extract;
 			r->st.ms_extract = 0.f;

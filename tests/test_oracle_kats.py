@@ -152,3 +152,56 @@ def test_btllib_unit_test_vector(oracle_build):
         hv = (ctypes.c_uint64 * 3)()
         lib.ora_extend_hashes((fh + rh) & (2**64 - 1), k, 3, hv)
         assert tuple(hv) == w
+
+
+def test_btllib_kit_our_side_matches_the_oracle(tmp_path, oracle_build):
+    """tests/tools/verify_btllib.sh compares real btllib with dump_ours (the product's nte_common.h + bfio.cpp on the
+    host).  btllib is not in this image, so here only the kit's own half is checked: dump_ours agrees with the oracle on
+    the kit's fixed inputs (hashes by seeding and rolling, the built filter file, contains())."""
+    import ctypes
+    import subprocess
+    import sys
+    kit = os.path.join(H.ROOT, "tests", "tools", "btllib_kit")
+    w = str(tmp_path)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", os.path.join(w, "dump_ours"), os.path.join(kit, "dump_ours.cpp"),
+                    os.path.join(H.ROOT, "ntedit_amd", "host", "bfio.cpp"), os.path.join(H.ROOT, "ntedit_amd", "host", "params.cpp")],
+                   check=True)
+    subprocess.run([sys.executable, os.path.join(kit, "make_inputs.py"), w], check=True)
+    lib = H.oracle_lib()
+    for k in (25, 33, 64):
+        out = subprocess.run([os.path.join(w, "dump_ours"), "hashes", os.path.join(w, "acgt.txt"), str(k), "3"],
+                             capture_output=True, text=True, check=True).stdout.splitlines()
+        lines = [l for l in open(os.path.join(w, "acgt.txt")).read().splitlines() if len(l) >= k]
+        it = iter(out)
+        n = 0
+        for s in lines:
+            b = s.encode()
+            for i in range(len(s) - k + 1):
+                f = next(it).split()
+                fh = lib.ora_base_forward_hash(b[i:i + k], k)
+                rh = lib.ora_base_reverse_hash(b[i:i + k], k)
+                assert int(f[2], 16) == fh and int(f[3], 16) == rh, (k, i)
+                assert int(f[5], 16) == fh and int(f[6], 16) == rh, (k, i)  # rolled == seeded
+                hv = (ctypes.c_uint64 * 3)()
+                lib.ora_extend_hashes(ctypes.c_uint64((fh + rh) & (2 ** 64 - 1)), k, 3, hv)
+                assert [int(x, 16) for x in f[8:11]] == list(hv)
+                n += 1
+            assert next(it) == "--"
+        assert n > 800
+    # the filter the kit builds = the oracle's mkbf (array bytes), and its contains() = the oracle's screening
+    subprocess.run([os.path.join(w, "dump_ours"), "build", os.path.join(w, "genome.fa"), "25", "3", "1048576",
+                    os.path.join(w, "our.bf")], check=True, capture_output=True)
+    H.mkbf([os.path.join(w, "genome.fa")], os.path.join(w, "ora.bf"), k=25, hashes=3, nbytes=1048576)
+    assert subprocess.run([sys.executable, os.path.join(kit, "cmp_bf.py"), os.path.join(w, "our.bf"), os.path.join(w, "ora.bf")],
+                          capture_output=True).returncode == 0
+    q = subprocess.run([os.path.join(w, "dump_ours"), "query", os.path.join(w, "ora.bf"), os.path.join(w, "draft.txt")],
+                       capture_output=True, text=True, check=True).stdout.splitlines()
+    bf = H.load_bf(os.path.join(w, "ora.bf"))
+    qi = iter(q[1:])
+    for s in open(os.path.join(w, "draft.txt")).read().splitlines():
+        absent = np.unpackbits(H.oracle_screen(s.encode(), bf).view(np.uint8), bitorder="little")
+        for i in range(len(s) - 25 + 1):
+            got = int(next(qi))
+            if "N" not in s[i:i + 25]:  # (the screening bitmap only speaks about k-mers of accepted bases)
+                assert got == 1 - int(absent[i]), i
+        assert next(qi) == "--"

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="${@:---bases 3e9 --steps 2 --warmup 1 --no-cpu-baseline --no-gather}"
+ARGS="${@:---bases 3e9 --steps 2 --warmup 1 --no-cpu-baseline --no-gather --no-regions}"
 # pass 1: kernel trace + stats (no counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace.err
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
@@ -38,6 +38,31 @@ PY
   rm -rf $OUT/pmc$i
 done
 rm -rf $OUT/trace
+# per-launch HBM traffic of our kernels (fabric read requests x 64 B + WRITE_SIZE KiB x 1024), for bench.py's roofline.traffic
+python - "$OUT/pmc_summary.txt" "$OUT/roofline_traffic.json" "$TAG" <<'PY'
+import json, re, sys
+txt, out, tag = open(sys.argv[1]).read(), sys.argv[2], sys.argv[3]
+agg = {}
+for line in txt.splitlines():
+    m = re.match(r"(.*?) dispatches=(\d+) (.*)", line)
+    if not m or "nte::" not in m.group(1):
+        continue
+    name = re.sub(r"^void ", "", m.group(1)).split("(")[0].replace("nte::", "")
+    d = agg.setdefault(name, {"dispatches": int(m.group(2))})
+    for kv in m.group(3).split():
+        k, v = kv.split("=")
+        d[k] = float(v)
+res = {}
+for name, d in agg.items():
+    n = d["dispatches"]
+    if "TCC_EA0_RDREQ_sum" in d and "WRITE_SIZE" in d:
+        res[name] = {"launches": n, "fetch_bytes_per_launch": d["TCC_EA0_RDREQ_sum"] * 64 / n,
+                     "fetch_size_kib_per_launch": d.get("FETCH_SIZE", 0) / n,
+                     "write_bytes_per_launch": d["WRITE_SIZE"] * 1024 / n,
+                     "tcc_hit_rate": d["TCC_HIT_sum"] / max(1.0, d["TCC_HIT_sum"] + d["TCC_MISS_sum"]) if "TCC_HIT_sum" in d else None}
+json.dump({"source": "profiles/%s_pmc_summary.txt (rocprofv3 --pmc, one counter group per run; reads = TCC_EA0_RDREQ x 64 B, writes = WRITE_SIZE KiB x 1024)" % tag,
+           "kernels": res}, open(out, "w"), indent=1)
+PY
 ls -la $OUT
 head -30 $OUT/kernel_stats.csv
 cat $OUT/pmc_summary.txt

@@ -167,7 +167,7 @@ def measured_regions(job, pol, args):
         out["kernel_region_host"] = {
             "value": round(job.n_bases / best[0] / 1e3, 2), "unit": "Mbases/s", "ms_per_call": round(best[0], 3),
             "gpu_timeline_ms": round(best[1], 3), "screen_ms_incl_copy_waits": round(best[2], 3),
-            "h2d_pieces": int(best[3]),
+            "screen_launches": int(best[3]),
             "note": "page-locked host batch -> edit records in host memory, one ntedit_hip_polish_batch call "
                     "(wall clock, best of 2 after a warm-up); H2D in pieces overlapped with screening"}
     except Exception as e:  # pragma: no cover

@@ -75,6 +75,8 @@ struct ntedit_hip_ctx
 	std::vector<hipEvent_t> h2d_ev;   // one per host-to-device piece of a host-resident batch
 	std::vector<hipEvent_t> bin_ev;   // 3 per record chunk of the binned screening (start, partitioned, probed)
 	u32 bin_chunks_last = 0;          // chunks of the last binned screening (0: the direct kernel ran)
+	u64 h2d_piece_bytes = 0;          // > 0: the batch is arriving from the host in pieces of this size on stream2
+	u64 h2d_pieces = 0;               //      (h2d_ev[i] = piece i is in HBM); the binned screening waits chunk by chunk
 	DevFilter filt[2];
 	ntedit_hip_params hp;
 	DevParams dp;
@@ -496,6 +498,14 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 			c->bin_ev.push_back(e);
 		}
 		hipEvent_t* tev = &c->bin_ev[3 * (size_t)chunk_no];
+		if (c->h2d_piece_bytes) {
+			// the chunk's bases (+ the k-1 behind its end) must have arrived
+			u64 piece = (end + SCREEN_TILE) / c->h2d_piece_bytes;
+			if (piece >= c->h2d_pieces) {
+				piece = c->h2d_pieces - 1;
+			}
+			HIP_TRY(c, hipStreamWaitEvent(stream, c->h2d_ev[piece], 0));
+		}
 		HIP_TRY(c, hipMemsetAsync(c->bin_work.p, 0, (size_t)(n_slices + 1) * 4, stream));
 		HIP_TRY(c, hipEventRecord(tev[0], stream));
 		if ((rc = run_wc_partition(c, stream, a, blocks))) {
@@ -1234,12 +1244,29 @@ ntedit_hip_polish_batch(
 			}
 			HIP_BAIL(hipEventRecord(c->chunk_ev[1], sA));
 		} else if (!pipelined) {
+			c->h2d_piece_bytes = 0;
 			if (h2d_overlap && attempt == 0) {
-				// (the binned pipeline: the batch goes over in one piece; a retry finds it in HBM already)
-				HIP_BAIL(hipMemcpyAsync(c->seq.p, bases, n, hipMemcpyHostToDevice, sA));
+				// the binned pipeline: all pieces are queued on stream B right away (page-locked memory: truly
+				// asynchronous, at link speed) and every record chunk waits for its own bases only; a retry
+				// finds the batch in HBM already
+				const u64 n_pieces = (n + h2d_piece - 1) / h2d_piece;
+				while (c->h2d_ev.size() < n_pieces) {
+					hipEvent_t e;
+					HIP_BAIL(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+					c->h2d_ev.push_back(e);
+				}
+				for (u64 j = 0; j < n_pieces; j++) {
+					const u64 o = j * h2d_piece, len = o + h2d_piece < n ? h2d_piece : n - o;
+					HIP_BAIL(hipMemcpyAsync((char*)c->seq.p + o, bases + o, len, hipMemcpyHostToDevice, sB));
+					HIP_BAIL(hipEventRecord(c->h2d_ev[j], sB));
+				}
+				c->h2d_piece_bytes = h2d_piece;
+				c->h2d_pieces = n_pieces;
 			}
 			HIP_BAIL(hipEventRecord(c->chunk_ev[0], sA));
-			if ((rc = launch_screen<false>(c, d_seq, n, f0, d_bitmap, n_words))) {
+			rc = launch_screen<false>(c, d_seq, n, f0, d_bitmap, n_words);
+			c->h2d_piece_bytes = 0;
+			if (rc) {
 				return bail(rc);
 			}
 			HIP_BAIL(hipEventRecord(c->chunk_ev[1], sA));

@@ -1036,96 +1036,124 @@ ntedit_hip_screen(ntedit_hip_ctx* c, const char* bases, uint64_t n, int on_devic
 	return 0;
 }
 
-int
-ntedit_hip_polish_batch(
-    ntedit_hip_ctx* c,
-    const char* bases,
-    uint64_t n,
-    const uint64_t* offsets,
-    const uint32_t* lens,
-    uint32_t n_contigs,
-    int on_device,
-    ntedit_hip_result** out)
+} // extern "C"
+
+// ---- ntedit_hip_polish_batch, in stages --------------------------------------------------------------------
+// plan()              chunk plan (whole contigs per pipeline chunk), staging of the batch, grow-only buffers
+// launch_screening()  stream A: step 1 for every k-mer of the batch (direct or binned; H2D pieces underneath)
+// run_chunk_events()  stream B, per chunk: absent bitmap -> ordered event list -> the event machine in rounds
+// collect()           edit records to page-locked host memory; events parked by the budget are resolved in serial
+//                     order and re-run (host/resolve.h)
+// finish()            timings
+namespace {
+
+struct PolishRun
 {
-	if (!c || !out || (n && !bases) || (n_contigs && (!offsets || !lens))) {
-		return fail(c, NTEDIT_E_ARG, "polish_batch: bad argument");
-	}
-	*out = nullptr;
-	HIP_TRY(c, hipSetDevice(c->device));
-	int rc = refresh_params(c);
-	if (rc) {
-		return rc;
-	}
-	for (u32 i = 0; i < n_contigs; i++) {
-		if (offsets[i] + lens[i] > n || (i + 1 < n_contigs && offsets[i] + lens[i] >= offsets[i + 1])) {
-			return fail(c, NTEDIT_E_ARG, "polish_batch: contig %u breaks the batch layout", i);
-		}
-	}
-	ntedit_hip_result* r = new ntedit_hip_result();
-	r->owner = c;
-	memset(&r->st, 0, sizeof r->st);
-	r->st.bases = n;
-	r->snv = c->hp.snv ? 1 : 0;
-	*out = r;
-	if (n == 0 || n_contigs == 0) {
-		return 0;
-	}
-	PinBuf early; // pass-1 edit records copied to the host while pass 2 runs
-	early.p = nullptr;
-	early.cap = 0;
+	// the call
+	ntedit_hip_ctx* c;
+	const char* bases;
+	u64 n;
+	const uint64_t* offsets;
+	const uint32_t* lens;
+	u32 n_contigs;
+	int on_device;
+	ntedit_hip_result* r;
+
+	// plan
+	struct Chunk
+	{
+		u32 c0, c1; // contigs [c0, c1)
+		u64 b0, b1; // byte range of those contigs (incl. their separators)
+		u64 t0, t1; // screening tiles
+	};
+	std::vector<Chunk> chunks;
+	size_t n_ch = 0;
+	bool pipelined = false;
+	u64 n_words = 0;
+	const u8* d_seq = nullptr;
+	u64* d_bitmap = nullptr;
+	hipStream_t sA = nullptr; // screening
+	hipStream_t sB = nullptr; // event extraction + event machine (and H2D pieces while the screening runs)
+	u32 grid = 0;
+	u64 grid_lo = 0;
+	Filter f0;
+	size_t screen_pad = 0;
+	u64 h2d_piece = 0;
+	bool h2d_overlap = false;
+	u64 arena_chunks = 0;
+
+	// one attempt (the batch is run again with more room when the arena or a rope window overflows)
+	PinBuf early; // pass-1 edit records copied to the host while the sweeps run
 	u64 early_chunks = 0;
-	auto bail = [&](int code) {
-		(void)hipDeviceSynchronize(); // an early copy may still be in flight
+	u32 h2d_launches = 0;
+	u32 status = 0;
+	u64 ev_total = 0, absent_total = 0, deferred_total = 0, skipped_total = 0;
+	float ms_machine = 0.f;
+	bool first_b = true;
+	MachineArgs keep_a; // the last chunk's launch arguments (re-runs of parked events)
+	// counters layout (bytes): [0] absent k-mers u64, [8] starts of the current chunk u64, [32] arena cursor u32,
+	// [40] status u32, [44] deferred count u32, [52] parked events u32, [60] work counter u32, [64] round list length u32
+	unsigned long long* d_counters = nullptr;
+	u32 *d_arena_next = nullptr, *d_status = nullptr, *d_ndef = nullptr, *d_list_n = nullptr;
+
+	PolishRun()
+	{
+		early.p = nullptr;
+		early.cap = 0;
+		memset(&keep_a, 0, sizeof keep_a);
+	}
+
+	// a failure from anywhere: nothing may leak (an early copy may still be in flight), *out stays null
+	int bail(int code)
+	{
+		(void)hipDeviceSynchronize();
 		pin_give(c, early);
 		pin_give(c, r->arena_buf);
 		pin_give(c, r->first_buf);
 		delete r;
-		*out = nullptr;
+		r = nullptr;
 		return code;
-	};
+	}
 
-	// a HIP error from here on must not leak the result and its pinned buffers (nor leave *out set)
-#define HIP_BAIL(expr)                                                                           \
-	do {                                                                                         \
-		hipError_t e_ = (expr);                                                                  \
-		if (e_ != hipSuccess) {                                                                  \
-			return bail(fail(c, NTEDIT_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)));       \
-		}                                                                                        \
-	} while (0)
-	const u64 n_words = (n + 63) / 64;
-	const u8* d_seq = nullptr;
+	int plan();
+	int begin_attempt();
+	int launch_screening(int attempt);
+	void launch_wave_pass(MachineArgs a, const u32* list, u32 count);
+	int run_chunk_events(size_t j);
+	int collect(bool* redo);
+	int finish();
+};
+
+int
+PolishRun::plan()
+{
+	int rc;
+	n_words = (n + 63) / 64;
 	// A batch that arrives in host memory crosses PCIe in pieces while the pieces that are already in HBM are
 	// being screened (SURVEY 8d "kernel region": host buffer in, edit records out).  Page-locked buffers
 	// (ntedit_hip_host_alloc, or any hipHostMalloc / registered memory) copy asynchronously at link speed;
 	// pageable ones are staged by the runtime, the overlap is the same.
-	u64 h2d_piece = 128ull << 20;
+	h2d_piece = 128ull << 20;
 	if (const char* e = getenv("NTEDIT_HIP_H2D_PIECE")) { // tests / tuning: bytes per piece (0 = one copy up front)
 		h2d_piece = strtoull(e, nullptr, 10) / SCREEN_TILE * SCREEN_TILE;
 	}
-	const bool h2d_overlap = !on_device && h2d_piece > 0 && n > 2 * h2d_piece;
+	h2d_overlap = !on_device && h2d_piece > 0 && n > 2 * h2d_piece;
 	if ((rc = stage_bases(c, bases, n, on_device, &d_seq, !h2d_overlap))) {
-		return bail(rc);
+		return rc;
 	}
 	if ((rc = ensure(c, c->bitmap, (n_words + 1) * 8)) || (rc = ensure(c, c->counters, 256)) ||
 	    (rc = ensure(c, c->offs, (size_t)n_contigs * 8)) || (rc = ensure(c, c->lens, (size_t)n_contigs * 4))) {
-		return bail(rc);
+		return rc;
 	}
-	u64* d_bitmap = (u64*)c->bitmap.p;
-	hipStream_t sA = c->stream;  // screening
-	hipStream_t sB = c->stream2; // event extraction + event machine
-	HIP_BAIL(hipMemcpyAsync(c->offs.p, offsets, (size_t)n_contigs * 8, hipMemcpyHostToDevice, sA));
-	HIP_BAIL(hipMemcpyAsync(c->lens.p, lens, (size_t)n_contigs * 4, hipMemcpyHostToDevice, sA));
+	d_bitmap = (u64*)c->bitmap.p;
+	sA = c->stream;
+	sB = c->stream2;
+	HIP_TRY(c, hipMemcpyAsync(c->offs.p, offsets, (size_t)n_contigs * 8, hipMemcpyHostToDevice, sA));
+	HIP_TRY(c, hipMemcpyAsync(c->lens.p, lens, (size_t)n_contigs * 4, hipMemcpyHostToDevice, sA));
 
 	// ---- chunk plan: whole contigs, cut at SCREEN_TILE boundaries of the screening pass.
 	// Chunk j's screening covers tiles [t0, t1) with t1 = ceil(end of its last contig / TILE),
 	// so everything its events can touch has been screened when its screening launch ends.
-	struct Chunk
-	{
-		u32 c0, c1;   // contigs [c0, c1)
-		u64 b0, b1;   // byte range of those contigs (incl. their separators)
-		u64 t0, t1;   // screening tiles
-	};
-	std::vector<Chunk> chunks;
 	{
 		const u64 total_tiles = (n + SCREEN_TILE - 1) / SCREEN_TILE;
 		// Measured (3 Gbp, MI355X): overlapping the event machine of chunk j with the screening
@@ -1165,583 +1193,670 @@ ntedit_hip_polish_batch(
 			c0 = c1;
 		}
 	}
-	const size_t n_ch = chunks.size();
-	const bool pipelined = n_ch > 1;
+	n_ch = chunks.size();
+	pipelined = n_ch > 1;
 	while (c->chunk_ev.size() < 2 * n_ch) {
 		hipEvent_t e;
-		HIP_BAIL(hipEventCreate(&e));
+		HIP_TRY(c, hipEventCreate(&e));
 		c->chunk_ev.push_back(e);
 	}
-
-	const u32 grid = c->dp.start_grid;
-	u64 grid_lo = 0;
+	grid = c->dp.start_grid;
+	grid_lo = 0;
 	if (grid < 64) {
 		for (u32 b = 0; b < 64; b += grid) {
 			grid_lo |= 1ULL << b;
 		}
 	}
-	const Filter f0 = dev_filter(c->filt[0]);
+	f0 = dev_filter(c->filt[0]);
 	// with more than one chunk the screening kernel is held to 2 workgroups per CU (its speed
 	// is set by the L2-miss path, not by occupancy) so the machine kernels of the previous
 	// chunk get wave slots, registers and LDS on every CU
-	const size_t screen_pad = pipelined ? 44 * 1024 : 0;
-
-	u64 arena_chunks = n / 160 + 65536;
+	screen_pad = pipelined ? 44 * 1024 : 0;
+	arena_chunks = n / 160 + 65536;
 	if (arena_chunks * CHUNK_ITEMS * sizeof(Item) < c->arena.cap) {
 		arena_chunks = c->arena.cap / (CHUNK_ITEMS * sizeof(Item));
 	}
-	for (int attempt = 0;; attempt++) {
-		pin_give(c, early); // (streams are idle here)
-		early_chunks = 0;
-		if (arena_chunks > 0xFFFFFFF0ull) {
-			return bail(fail(c, NTEDIT_E_OVERFLOW, "edit-record arena exceeds 2^32 chunks"));
-		}
-		if ((rc = ensure(c, c->arena, arena_chunks * CHUNK_ITEMS * sizeof(Item)))) {
-			return bail(rc);
-		}
-		// counters layout (bytes): [0] absent k-mers u64, [8] starts of the current chunk u64,
-		// [32] arena cursor u32, [40] status u32, [44] deferred count u32
-		HIP_BAIL(hipMemsetAsync(c->counters.p, 0, 256, sA));
-		HIP_BAIL(hipStreamSynchronize(sA));
-		unsigned long long* d_counters = (unsigned long long*)c->counters.p;
-		u32* d_arena_next = (u32*)((char*)c->counters.p + 32);
-		u32* d_status = (u32*)((char*)c->counters.p + 40);
-		u32* d_ndef = (u32*)((char*)c->counters.p + 44);
+	return 0;
+}
 
-		// ---- stream A: every chunk's screening, back to back
-		HIP_BAIL(hipEventRecord(c->ev[0], sA));
-		u32 h2d_launches = 0;
-		u32 slog_unused = 0, nsl_unused = 0;
-		if (!pipelined && h2d_overlap && attempt == 0 && !binned_applicable(c, f0, n, &slog_unused, &nsl_unused)) {
-			// piece j+1 is copied (stream B is idle until the screening is done) while piece j is screened;
-			// the tiles of piece j read k-1 bases of piece j+1, so their launch waits for that copy
-			const u64 n_pieces = (n + h2d_piece - 1) / h2d_piece;
-			while (c->h2d_ev.size() < n_pieces) {
-				hipEvent_t e;
-				HIP_BAIL(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-				c->h2d_ev.push_back(e);
+int
+PolishRun::begin_attempt()
+{
+	int rc;
+	pin_give(c, early); // (streams are idle here)
+	early_chunks = 0;
+	if (arena_chunks > 0xFFFFFFF0ull) {
+		return fail(c, NTEDIT_E_OVERFLOW, "edit-record arena exceeds 2^32 chunks");
+	}
+	if ((rc = ensure(c, c->arena, arena_chunks * CHUNK_ITEMS * sizeof(Item)))) {
+		return rc;
+	}
+	HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 256, sA));
+	HIP_TRY(c, hipStreamSynchronize(sA));
+	d_counters = (unsigned long long*)c->counters.p;
+	d_arena_next = (u32*)((char*)c->counters.p + 32);
+	d_status = (u32*)((char*)c->counters.p + 40);
+	d_ndef = (u32*)((char*)c->counters.p + 44);
+	d_list_n = (u32*)((char*)c->counters.p + 64);
+	h2d_launches = 0;
+	status = 0;
+	ev_total = absent_total = deferred_total = skipped_total = 0;
+	ms_machine = 0.f;
+	first_b = true;
+	return 0;
+}
+
+// stream A: every chunk's screening, back to back
+int
+PolishRun::launch_screening(int attempt)
+{
+	int rc;
+	HIP_TRY(c, hipEventRecord(c->ev[0], sA));
+	u32 slog_unused = 0, nsl_unused = 0;
+	const bool binned = binned_applicable(c, f0, n, &slog_unused, &nsl_unused);
+	const u64 n_pieces = h2d_piece ? (n + h2d_piece - 1) / h2d_piece : 0;
+	if (h2d_overlap && attempt == 0 && !pipelined) {
+		while (c->h2d_ev.size() < n_pieces) {
+			hipEvent_t e;
+			HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			c->h2d_ev.push_back(e);
+		}
+	}
+	auto copy_piece = [&](u64 j) -> hipError_t {
+		const u64 o = j * h2d_piece, len = o + h2d_piece < n ? h2d_piece : n - o;
+		hipError_t e = hipMemcpyAsync((char*)c->seq.p + o, bases + o, len, hipMemcpyHostToDevice, sB);
+		return e != hipSuccess ? e : hipEventRecord(c->h2d_ev[j], sB);
+	};
+	if (!pipelined && h2d_overlap && attempt == 0 && !binned) {
+		// direct kernel: piece j+1 is copied (stream B is idle until the screening is done) while piece j is
+		// screened; the tiles of piece j read k-1 bases of piece j+1, so their launch waits for that copy
+		HIP_TRY(c, hipEventRecord(c->chunk_ev[0], sA));
+		HIP_TRY(c, copy_piece(0));
+		const u64 tiles_per_piece = h2d_piece / SCREEN_TILE;
+		const u64 total_tiles = (n + SCREEN_TILE - 1) / SCREEN_TILE;
+		for (u64 j = 0; j < n_pieces; j++) {
+			if (j + 1 < n_pieces) {
+				HIP_TRY(c, copy_piece(j + 1));
 			}
-			HIP_BAIL(hipEventRecord(c->chunk_ev[0], sA));
-			auto copy_piece = [&](u64 j) -> hipError_t {
-				const u64 o = j * h2d_piece, len = o + h2d_piece < n ? h2d_piece : n - o;
-				hipError_t e = hipMemcpyAsync((char*)c->seq.p + o, bases + o, len, hipMemcpyHostToDevice, sB);
-				return e != hipSuccess ? e : hipEventRecord(c->h2d_ev[j], sB);
-			};
-			HIP_BAIL(copy_piece(0));
-			const u64 tiles_per_piece = h2d_piece / SCREEN_TILE;
-			const u64 total_tiles = (n + SCREEN_TILE - 1) / SCREEN_TILE;
+			HIP_TRY(c, hipStreamWaitEvent(sA, c->h2d_ev[j + 1 < n_pieces ? j + 1 : j], 0));
+			const u64 t0 = j * tiles_per_piece;
+			const u64 t1 = j + 1 < n_pieces ? t0 + tiles_per_piece : total_tiles;
+			if ((rc = launch_screen_tiles<false>(c, sA, d_seq, n, f0, d_bitmap, n_words, t0, t1 - t0, 0))) {
+				return rc;
+			}
+			h2d_launches++;
+		}
+		HIP_TRY(c, hipEventRecord(c->chunk_ev[1], sA));
+	} else if (!pipelined) {
+		c->h2d_piece_bytes = 0;
+		if (h2d_overlap && attempt == 0) {
+			// the binned pipeline: all pieces are queued on stream B right away (page-locked memory: truly
+			// asynchronous, at link speed) and every record chunk waits for its own bases only; a retry
+			// finds the batch in HBM already
 			for (u64 j = 0; j < n_pieces; j++) {
-				if (j + 1 < n_pieces) {
-					HIP_BAIL(copy_piece(j + 1));
-				}
-				HIP_BAIL(hipStreamWaitEvent(sA, c->h2d_ev[j + 1 < n_pieces ? j + 1 : j], 0));
-				const u64 t0 = j * tiles_per_piece;
-				const u64 t1 = j + 1 < n_pieces ? t0 + tiles_per_piece : total_tiles;
-				if ((rc = launch_screen_tiles<false>(c, sA, d_seq, n, f0, d_bitmap, n_words, t0, t1 - t0, 0))) {
-					return bail(rc);
-				}
-				h2d_launches++;
+				HIP_TRY(c, copy_piece(j));
 			}
-			HIP_BAIL(hipEventRecord(c->chunk_ev[1], sA));
-		} else if (!pipelined) {
-			c->h2d_piece_bytes = 0;
-			if (h2d_overlap && attempt == 0) {
-				// the binned pipeline: all pieces are queued on stream B right away (page-locked memory: truly
-				// asynchronous, at link speed) and every record chunk waits for its own bases only; a retry
-				// finds the batch in HBM already
-				const u64 n_pieces = (n + h2d_piece - 1) / h2d_piece;
-				while (c->h2d_ev.size() < n_pieces) {
-					hipEvent_t e;
-					HIP_BAIL(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-					c->h2d_ev.push_back(e);
-				}
-				for (u64 j = 0; j < n_pieces; j++) {
-					const u64 o = j * h2d_piece, len = o + h2d_piece < n ? h2d_piece : n - o;
-					HIP_BAIL(hipMemcpyAsync((char*)c->seq.p + o, bases + o, len, hipMemcpyHostToDevice, sB));
-					HIP_BAIL(hipEventRecord(c->h2d_ev[j], sB));
-				}
-				c->h2d_piece_bytes = h2d_piece;
-				c->h2d_pieces = n_pieces;
+			c->h2d_piece_bytes = h2d_piece;
+			c->h2d_pieces = n_pieces;
+		}
+		HIP_TRY(c, hipEventRecord(c->chunk_ev[0], sA));
+		rc = launch_screen<false>(c, d_seq, n, f0, d_bitmap, n_words);
+		c->h2d_piece_bytes = 0;
+		if (rc) {
+			return rc;
+		}
+		HIP_TRY(c, hipEventRecord(c->chunk_ev[1], sA));
+	} else {
+		if (h2d_overlap && attempt == 0) {
+			HIP_TRY(c, hipMemcpyAsync(c->seq.p, bases, n, hipMemcpyHostToDevice, sA));
+		}
+		for (size_t j = 0; j < n_ch; j++) {
+			HIP_TRY(c, hipEventRecord(c->chunk_ev[2 * j], sA));
+			if ((rc = launch_screen_tiles<false>(
+			         c, sA, d_seq, n, f0, d_bitmap, n_words, chunks[j].t0, chunks[j].t1 - chunks[j].t0, screen_pad))) {
+				return rc;
 			}
-			HIP_BAIL(hipEventRecord(c->chunk_ev[0], sA));
-			rc = launch_screen<false>(c, d_seq, n, f0, d_bitmap, n_words);
-			c->h2d_piece_bytes = 0;
-			if (rc) {
-				return bail(rc);
+			HIP_TRY(c, hipEventRecord(c->chunk_ev[2 * j + 1], sA));
+		}
+	}
+	HIP_TRY(c, hipEventRecord(c->ev[1], sA));
+	return 0;
+}
+
+// the wavefront-per-event kernel over a list of events of the current chunk
+void
+PolishRun::launch_wave_pass(MachineArgs a, const u32* list, u32 count)
+{
+	a.defer = 0;
+	a.ev_list = list;
+	a.n_events = count;
+	const u64 per_block = (u64)MACHINE_TPB / (u64)machine_wave_group();
+	const u64 want2 = ((u64)count + per_block - 1) / per_block;
+	const u64 cap2 = (u64)c->cu_count * 8;
+	const u64 b2 = want2 < cap2 ? want2 : cap2;
+	// the wave kernel runs few events per block: window and workspace both fit in LDS
+	size_t dyn2 = a.win_in_lds ? (size_t)a.win_bytes * per_block : 0;
+	const u64 Wn = a.p.node_window;
+	const u64 w16 = (Wn + 15) & ~15ull;
+	const u64 slab = Wn * 16 + w16 * 4 + w16 * 2 + w16 + w16;
+	const u64 win_area = ((u64)a.win_bytes * per_block + 15) & ~15ull;
+	if (win_area + slab * per_block <= 40 * 1024 && !getenv("NTEDIT_HIP_NO_LDS_WS")) {
+		a.win_in_lds = 1;
+		a.lds_ws_off = (u32)win_area;
+		a.lds_slab = (u32)slab;
+		dyn2 = (size_t)(win_area + slab * per_block);
+	}
+	(void)hipMemsetAsync(a.work_counter, 0, 4, sB);
+	launch_k_machine_wave((unsigned)b2, dyn2, sB, a);
+}
+
+// stream B, chunk j: as soon as its screening is done
+int
+PolishRun::run_chunk_events(size_t j)
+{
+	int rc;
+	const Chunk& ch = chunks[j];
+	HIP_TRY(c, hipStreamWaitEvent(sB, c->chunk_ev[2 * j + 1], 0));
+	if (first_b) {
+		HIP_TRY(c, hipEventRecord(c->ev[2], sB));
+		first_b = false;
+	}
+	// ---- absent bitmap -> ordered event list (count, single-workgroup scan, write)
+	const u64 w0 = ch.b0 / 64, w1 = (ch.b1 + 63) / 64;
+	const u64 n_sblocks = (w1 - w0 + ST_TPB - 1) / ST_TPB;
+	if (n_sblocks == 0) {
+		return 0;
+	}
+	if ((rc = ensure(c, c->block_counts, n_sblocks * 4)) || (rc = ensure(c, c->block_offsets, n_sblocks * 8))) {
+		return rc;
+	}
+	HIP_TRY(c, hipMemsetAsync((char*)c->counters.p + 8, 0, 8, sB));
+	hipLaunchKernelGGL(
+	    k_count_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_bitmap, w0, w1, ch.b0, ch.b1, grid_lo, grid,
+	    (u32*)c->block_counts.p, d_counters);
+	hipLaunchKernelGGL(
+	    k_scan_counts, dim3(1), dim3(1024), 0, sB, (const u32*)c->block_counts.p, n_sblocks,
+	    (unsigned long long*)c->block_offsets.p, d_counters);
+	unsigned long long h_counters[2] = { 0, 0 };
+	HIP_TRY(c, hipMemcpyAsync(h_counters, d_counters, 16, hipMemcpyDeviceToHost, sB));
+	HIP_TRY(c, hipStreamSynchronize(sB));
+	const u64 n_ev = h_counters[1];
+	absent_total = h_counters[0];
+	if (n_ev == 0) {
+		return 0;
+	}
+	if (ev_total + n_ev > 0xFFFFFFF0ull) {
+		return fail(c, NTEDIT_E_OVERFLOW, "more than 2^32 events in one batch");
+	}
+	// grow-only buffers; (re)allocation happens on the first batches only
+	if (ev_total + n_ev > c->events.cap / 8 || ev_total + n_ev > c->first_chunk.cap / 4) {
+		// keep what earlier chunks wrote: allocate bigger buffers and copy
+		const u64 want = (ev_total + n_ev) * 2 + 1024;
+		DevBuf ne, nf;
+		if ((rc = ensure(c, ne, want * 8)) || (rc = ensure(c, nf, want * 4))) {
+			return rc;
+		}
+		if (ev_total) {
+			HIP_TRY(c, hipMemcpyAsync(ne.p, c->events.p, ev_total * 8, hipMemcpyDeviceToDevice, sB));
+			HIP_TRY(c, hipMemcpyAsync(nf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToDevice, sB));
+			HIP_TRY(c, hipStreamSynchronize(sB));
+		}
+		release(c->events);
+		release(c->first_chunk);
+		c->events = ne;
+		c->first_chunk = nf;
+	}
+	if ((rc = ensure(c, c->deferred, n_ev * 4))) {
+		return rc;
+	}
+	u64* d_events = (u64*)c->events.p + ev_total;
+	u32* d_first = (u32*)c->first_chunk.p + ev_total;
+	hipLaunchKernelGGL(
+	    k_write_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_bitmap, w0, w1, ch.b0, ch.b1, grid_lo, grid,
+	    (const unsigned long long*)c->block_offsets.p, d_events);
+
+	// ---- the machine's launch arguments and per-thread workspace
+	const u64 max_threads = (u64)c->cu_count * 2048;
+	u64 threads = n_ev < max_threads ? n_ev : max_threads;
+	const u64 blocks = (threads + MACHINE_TPB - 1) / MACHINE_TPB;
+	threads = blocks * MACHINE_TPB;
+	const u64 W = c->dp.node_window;
+	if ((rc = ensure(c, c->ws_nodes, threads * W * sizeof(Node))) || (rc = ensure(c, c->ws_ov_pos, threads * W * 4)) ||
+	    (rc = ensure(c, c->ws_ov_chr, threads * W)) || (rc = ensure(c, c->ws_prev, threads * W)) ||
+	    (rc = ensure(c, c->ws_lps, threads * W * 2))) {
+		return rc;
+	}
+	MachineArgs a;
+	a.seq = d_seq;
+	a.n_bytes = n;
+	a.offsets = (const u64*)c->offs.p;
+	a.lens = (const u32*)c->lens.p;
+	a.n_contigs = n_contigs;
+	a.bitmap = d_bitmap;
+	a.events = d_events;
+	a.n_events = n_ev;
+	a.tabs = c->d_tab;
+	a.p = c->dp;
+	a.bloom = f0;
+	a.rep = c->filt[1].set ? dev_filter(c->filt[1]) : f0;
+	a.ws_nodes = (Node*)c->ws_nodes.p;
+	a.ws_ov_pos = (u32*)c->ws_ov_pos.p;
+	a.ws_ov_chr = (u8*)c->ws_ov_chr.p;
+	a.ws_prev = (u8*)c->ws_prev.p;
+	a.ws_lps = (int16_t*)c->ws_lps.p;
+	a.win_bytes = 2 * c->dp.k + c->dp.max_deletions + 8 + 32; // Machine::win_bytes() + slack
+	a.win_in_lds = (size_t)a.win_bytes * MACHINE_TPB <= 40 * 1024 ? 1 : 0;
+	a.ws_win = nullptr;
+	if (!a.win_in_lds) {
+		if ((rc = ensure(c, c->ws_win, threads * a.win_bytes))) {
+			return rc;
+		}
+		a.ws_win = (u8*)c->ws_win.p;
+	}
+	const size_t dyn_lds = a.win_in_lds ? (size_t)a.win_bytes * MACHINE_TPB : 0;
+	a.arena = (Item*)c->arena.p;
+	a.arena_next = d_arena_next;
+	a.arena_chunks = (u32)arena_chunks;
+	a.first_chunk = d_first;
+	a.status = d_status;
+	a.lds_ws_off = 0;
+	a.lds_slab = 0;
+	a.defer = 1;
+	a.ev_list = nullptr;
+	a.deferred = (u32*)c->deferred.p;
+	a.n_deferred = d_ndef;
+	a.n_unfinished = (u32*)((char*)c->counters.p + 52);
+	a.work_counter = (u32*)((char*)c->counters.p + 60);
+	if (n_ch != 1) {
+		a.p.event_budget = 0; // (parked events are re-run per batch: single-chunk batches only)
+	}
+
+	// ---- rounds (see "event rounds" in nte_kernels.hip): primaries, then the secondaries their
+	// primary's run does not overtake, then -- practically never -- whatever a verification rejects.
+	// Pipeline chunks and SNV mode run everything in one round.
+	const bool rounds = n_ch == 1 && !c->dp.snv && n_ev < 0xFFFFFF00ull && !getenv("NTEDIT_HIP_NO_ROUNDS");
+	u32* d_list = nullptr;
+	u64* d_before = nullptr;
+	u64* d_bmax = nullptr;
+	const u32 n32 = (u32)n_ev;
+	const u32 sel_blocks = (n32 + EVR_TPB - 1) / EVR_TPB;
+	const u32 pm_blocks = (n32 + 1023) / 1024;
+	a.ev_cover = nullptr;
+	a.ev_flags = nullptr;
+	if (rounds) {
+		if ((rc = ensure(c, c->ev_cover, n_ev * 8)) || (rc = ensure(c, c->ev_before, n_ev * 8)) ||
+		    (rc = ensure(c, c->ev_flags, n_ev)) || (rc = ensure(c, c->ev_list, n_ev * 4)) ||
+		    (rc = ensure(c, c->ev_bmax, (size_t)pm_blocks * 8 + 8))) {
+			return rc;
+		}
+		a.ev_cover = (u64*)c->ev_cover.p;
+		a.ev_flags = (u8*)c->ev_flags.p;
+		d_list = (u32*)c->ev_list.p;
+		d_before = (u64*)c->ev_before.p;
+		d_bmax = (u64*)c->ev_bmax.p;
+		HIP_TRY(c, hipMemsetAsync(a.ev_cover, 0, n_ev * 8, sB));
+	}
+	HIP_TRY(c, hipEventRecord(c->ev[3], sB));
+	u32 n_def = 0;
+	float p2_ms = 0.f;
+	// one round = pass 1 over a list of events (indel sweeps postponed), pass 2 over the postponed ones
+	auto run_round = [&](const u32* list, u32 count, bool first_round) -> int {
+		if (count == 0) {
+			return 0;
+		}
+		MachineArgs ra = a;
+		ra.ev_list = list;
+		ra.n_events = count;
+		HIP_TRY(c, hipMemsetAsync(d_ndef, 0, 4, sB));
+		HIP_TRY(c, hipMemsetAsync(ra.work_counter, 0, 4, sB));
+		const u64 want = ((u64)count + MACHINE_TPB - 1) / MACHINE_TPB;
+		launch_k_machine_thread((unsigned)(want < blocks ? want : blocks), dyn_lds, sB, ra);
+		HIP_TRY(c, hipGetLastError());
+		u32 h_tail[4] = { 0, 0, 0, 0 };
+		HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+		HIP_TRY(c, hipEventRecord(c->ev[5], sB));
+		HIP_TRY(c, hipStreamSynchronize(sB));
+		const u32 nd = h_tail[3];
+		n_def += nd;
+		status = h_tail[2];
+		if (first_round && nd > 0 && status == 0 && n_ch == 1 && !getenv("NTEDIT_HIP_NO_EARLY_COPY")) {
+			// everything pass 1 wrote is final (later launches only append chunks): start moving it
+			// to the host on the other stream while the sweeps run
+			early_chunks = h_tail[0] < arena_chunks ? h_tail[0] : arena_chunks;
+			const u64 room = early_chunks + (u64)nd * 3 + 4096;
+			int prc = pin_take(c, room * CHUNK_ITEMS * sizeof(Item) + 16, &early);
+			if (prc) {
+				return prc;
 			}
-			HIP_BAIL(hipEventRecord(c->chunk_ev[1], sA));
-		} else {
-			if (h2d_overlap && attempt == 0) {
-				HIP_BAIL(hipMemcpyAsync(c->seq.p, bases, n, hipMemcpyHostToDevice, sA));
-			}
-			for (size_t j = 0; j < n_ch; j++) {
-				HIP_BAIL(hipEventRecord(c->chunk_ev[2 * j], sA));
-				if ((rc = launch_screen_tiles<false>(
-				         c, sA, d_seq, n, f0, d_bitmap, n_words, chunks[j].t0, chunks[j].t1 - chunks[j].t0, screen_pad))) {
-					return bail(rc);
-				}
-				HIP_BAIL(hipEventRecord(c->chunk_ev[2 * j + 1], sA));
+			if (early_chunks) {
+				HIP_TRY(c, hipMemcpyAsync(early.p, c->arena.p, early_chunks * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sA));
 			}
 		}
-		HIP_BAIL(hipEventRecord(c->ev[1], sA));
-
-		// ---- stream B: per chunk, as soon as its screening is done
-		u64 ev_total = 0;      // events of the chunks processed so far
-		u64 absent_total = 0, deferred_total = 0, skipped_total = 0;
-		u32 status = 0;
-		float ms_extract = 0.f, ms_machine = 0.f;
-		bool first_b = true;
-		MachineArgs keep_a; // the last chunk's launch arguments (re-runs of parked events)
-		memset(&keep_a, 0, sizeof keep_a);
-		// the wavefront-per-event kernel over a list of events of the current chunk
-		auto launch_wave_pass = [&](MachineArgs a, const u32* list, u32 count) {
-			a.defer = 0;
-			a.ev_list = list;
-			a.n_events = count;
-			const u64 per_block = (u64)MACHINE_TPB / (u64)machine_wave_group();
-			const u64 want2 = ((u64)count + per_block - 1) / per_block;
-			const u64 cap2 = (u64)c->cu_count * 8;
-			const u64 b2 = want2 < cap2 ? want2 : cap2;
-			// the wave kernel runs few events per block: window and workspace both fit in LDS
-			size_t dyn2 = a.win_in_lds ? (size_t)a.win_bytes * per_block : 0;
-			const u64 Wn = a.p.node_window;
-			const u64 w16 = (Wn + 15) & ~15ull;
-			const u64 slab = Wn * 16 + w16 * 4 + w16 * 2 + w16 + w16;
-			const u64 win_area = ((u64)a.win_bytes * per_block + 15) & ~15ull;
-			if (win_area + slab * per_block <= 40 * 1024 && !getenv("NTEDIT_HIP_NO_LDS_WS")) {
-				a.win_in_lds = 1;
-				a.lds_ws_off = (u32)win_area;
-				a.lds_slab = (u32)slab;
-				dyn2 = (size_t)(win_area + slab * per_block);
+		if (nd > 0 && status == 0) {
+			MachineArgs a2 = ra;
+			if (const char* dbg = getenv("NTEDIT_HIP_PASS2_DEBUG")) {
+				a2.p.debug_stop = (u32)atoi(dbg); // timing ablations; results are NOT valid
 			}
-			(void)hipMemsetAsync(a.work_counter, 0, 4, sB);
-			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] wave launch: blocks %llu events %llu dyn %zu lds_slab %u counter %p\n", (unsigned long long)b2, (unsigned long long)a.n_events, dyn2, a.lds_slab, (void*)a.work_counter); }
-			launch_k_machine_wave((unsigned)b2, dyn2, sB, a);
-		};
-		for (size_t j = 0; j < n_ch && status == 0; j++) {
-			const Chunk& ch = chunks[j];
-			HIP_BAIL(hipStreamWaitEvent(sB, c->chunk_ev[2 * j + 1], 0));
-			if (first_b) {
-				HIP_BAIL(hipEventRecord(c->ev[2], sB));
-				first_b = false;
-			}
-			const u64 w0 = ch.b0 / 64, w1 = (ch.b1 + 63) / 64;
-			const u64 n_sblocks = (w1 - w0 + ST_TPB - 1) / ST_TPB;
-			if (n_sblocks == 0) {
-				continue;
-			}
-			if ((rc = ensure(c, c->block_counts, n_sblocks * 4)) || (rc = ensure(c, c->block_offsets, n_sblocks * 8))) {
-				return bail(rc);
-			}
-			HIP_BAIL(hipMemsetAsync((char*)c->counters.p + 8, 0, 8, sB));
-			hipLaunchKernelGGL(
-			    k_count_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_bitmap, w0, w1, ch.b0, ch.b1, grid_lo,
-			    grid, (u32*)c->block_counts.p, d_counters);
-			hipLaunchKernelGGL(
-			    k_scan_counts, dim3(1), dim3(1024), 0, sB, (const u32*)c->block_counts.p, n_sblocks,
-			    (unsigned long long*)c->block_offsets.p, d_counters);
-			unsigned long long h_counters[2] = { 0, 0 };
-			HIP_BAIL(hipMemcpyAsync(h_counters, d_counters, 16, hipMemcpyDeviceToHost, sB));
-			HIP_BAIL(hipStreamSynchronize(sB));
-			const u64 n_ev = h_counters[1];
-			absent_total = h_counters[0];
-			if (n_ev == 0) {
-				continue;
-			}
-			if (ev_total + n_ev > 0xFFFFFFF0ull) {
-				return bail(fail(c, NTEDIT_E_OVERFLOW, "more than 2^32 events in one batch"));
-			}
-			// grow-only buffers; (re)allocation happens on the first batches only
-			if (ev_total + n_ev > c->events.cap / 8 || ev_total + n_ev > c->first_chunk.cap / 4) {
-				// keep what earlier chunks wrote: allocate bigger buffers and copy
-				const u64 want = (ev_total + n_ev) * 2 + 1024;
-				DevBuf ne, nf;
-				if ((rc = ensure(c, ne, want * 8)) || (rc = ensure(c, nf, want * 4))) {
-					return bail(rc);
-				}
-				if (ev_total) {
-					HIP_BAIL(hipMemcpyAsync(ne.p, c->events.p, ev_total * 8, hipMemcpyDeviceToDevice, sB));
-					HIP_BAIL(hipMemcpyAsync(nf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToDevice, sB));
-					HIP_BAIL(hipStreamSynchronize(sB));
-				}
-				release(c->events);
-				release(c->first_chunk);
-				c->events = ne;
-				c->first_chunk = nf;
-			}
-			if ((rc = ensure(c, c->deferred, n_ev * 4))) {
-				return bail(rc);
-			}
-			u64* d_events = (u64*)c->events.p + ev_total;
-			u32* d_first = (u32*)c->first_chunk.p + ev_total;
-			hipLaunchKernelGGL(
-			    k_write_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_bitmap, w0, w1, ch.b0, ch.b1, grid_lo,
-			    grid, (const unsigned long long*)c->block_offsets.p, d_events);
-
-			const u64 max_threads = (u64)c->cu_count * 2048;
-			u64 threads = n_ev < max_threads ? n_ev : max_threads;
-			const u64 blocks = (threads + MACHINE_TPB - 1) / MACHINE_TPB;
-			threads = blocks * MACHINE_TPB;
-			const u64 W = c->dp.node_window;
-			if ((rc = ensure(c, c->ws_nodes, threads * W * sizeof(Node))) ||
-			    (rc = ensure(c, c->ws_ov_pos, threads * W * 4)) || (rc = ensure(c, c->ws_ov_chr, threads * W)) ||
-			    (rc = ensure(c, c->ws_prev, threads * W)) || (rc = ensure(c, c->ws_lps, threads * W * 2))) {
-				return bail(rc);
-			}
-			MachineArgs a;
-			a.seq = d_seq;
-			a.n_bytes = n;
-			a.offsets = (const u64*)c->offs.p;
-			a.lens = (const u32*)c->lens.p;
-			a.n_contigs = n_contigs;
-			a.bitmap = d_bitmap;
-			a.events = d_events;
-			a.n_events = n_ev;
-			a.tabs = c->d_tab;
-			a.p = c->dp;
-			a.bloom = f0;
-			a.rep = c->filt[1].set ? dev_filter(c->filt[1]) : f0;
-			a.ws_nodes = (Node*)c->ws_nodes.p;
-			a.ws_ov_pos = (u32*)c->ws_ov_pos.p;
-			a.ws_ov_chr = (u8*)c->ws_ov_chr.p;
-			a.ws_prev = (u8*)c->ws_prev.p;
-			a.ws_lps = (int16_t*)c->ws_lps.p;
-			a.win_bytes = 2 * c->dp.k + c->dp.max_deletions + 8 + 32; // Machine::win_bytes() + slack
-			a.win_in_lds = (size_t)a.win_bytes * MACHINE_TPB <= 40 * 1024 ? 1 : 0;
-			a.ws_win = nullptr;
-			if (!a.win_in_lds) {
-				if ((rc = ensure(c, c->ws_win, threads * a.win_bytes))) {
-					return bail(rc);
-				}
-				a.ws_win = (u8*)c->ws_win.p;
-			}
-			const size_t dyn_lds = a.win_in_lds ? (size_t)a.win_bytes * MACHINE_TPB : 0;
-			a.arena = (Item*)c->arena.p;
-			a.arena_next = d_arena_next;
-			a.arena_chunks = (u32)arena_chunks;
-			a.first_chunk = d_first;
-			a.status = d_status;
-			a.lds_ws_off = 0;
-			a.lds_slab = 0;
-			a.defer = 1;
-			a.ev_list = nullptr;
-			a.deferred = (u32*)c->deferred.p;
-			a.n_deferred = d_ndef;
-			a.n_unfinished = (u32*)((char*)c->counters.p + 52);
-			a.work_counter = (u32*)((char*)c->counters.p + 60);
-			if (n_ch != 1) {
-				a.p.event_budget = 0; // (parked events are re-run per batch: single-chunk batches only)
-			}
-			// ---- rounds (see "event rounds" in nte_kernels.hip): primaries, then the secondaries their
-			// primary's run does not overtake, then -- practically never -- whatever a verification rejects.
-			// Pipeline chunks and SNV mode run everything in one round.
-			const bool rounds = n_ch == 1 && !c->dp.snv && n_ev < 0xFFFFFF00ull && !getenv("NTEDIT_HIP_NO_ROUNDS");
-			u32* d_list = nullptr;
-			u32* d_list_n = (u32*)((char*)c->counters.p + 64);
-			u64* d_before = nullptr;
-			u64* d_bmax = nullptr;
-			const u32 n32 = (u32)n_ev;
-			const u32 sel_blocks = (n32 + EVR_TPB - 1) / EVR_TPB;
-			const u32 pm_blocks = (n32 + 1023) / 1024;
-			a.ev_cover = nullptr;
-			a.ev_flags = nullptr;
-			if (rounds) {
-				if ((rc = ensure(c, c->ev_cover, n_ev * 8)) || (rc = ensure(c, c->ev_before, n_ev * 8)) ||
-				    (rc = ensure(c, c->ev_flags, n_ev)) || (rc = ensure(c, c->ev_list, n_ev * 4)) ||
-				    (rc = ensure(c, c->ev_bmax, (size_t)pm_blocks * 8 + 8))) {
-					return bail(rc);
-				}
-				a.ev_cover = (u64*)c->ev_cover.p;
-				a.ev_flags = (u8*)c->ev_flags.p;
-				d_list = (u32*)c->ev_list.p;
-				d_before = (u64*)c->ev_before.p;
-				d_bmax = (u64*)c->ev_bmax.p;
-				HIP_BAIL(hipMemsetAsync(a.ev_cover, 0, n_ev * 8, sB));
-			}
-			HIP_BAIL(hipEventRecord(c->ev[3], sB));
-			u32 n_def = 0;
-			float p2_ms = 0.f;
-			// one round = pass 1 over a list of events (indel sweeps postponed), pass 2 over the postponed ones
-			auto run_round = [&](const u32* list, u32 count, bool first_round) -> int {
-				if (count == 0) {
-					return 0;
-				}
-				MachineArgs ra = a;
-				ra.ev_list = list;
-				ra.n_events = count;
-				HIP_TRY(c, hipMemsetAsync(d_ndef, 0, 4, sB));
-				HIP_TRY(c, hipMemsetAsync(ra.work_counter, 0, 4, sB));
-				const u64 want = ((u64)count + MACHINE_TPB - 1) / MACHINE_TPB;
-				launch_k_machine_thread((unsigned)(want < blocks ? want : blocks), dyn_lds, sB, ra);
-				HIP_TRY(c, hipGetLastError());
-				u32 h_tail[4] = { 0, 0, 0, 0 };
-				HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
-				HIP_TRY(c, hipEventRecord(c->ev[5], sB));
-				HIP_TRY(c, hipStreamSynchronize(sB));
-				const u32 nd = h_tail[3];
-				n_def += nd;
-				status = h_tail[2];
-				if (first_round && nd > 0 && status == 0 && n_ch == 1 && !getenv("NTEDIT_HIP_NO_EARLY_COPY")) {
-					// everything pass 1 wrote is final (later launches only append chunks): start moving it
-					// to the host on the other stream while the sweeps run
-					early_chunks = h_tail[0] < arena_chunks ? h_tail[0] : arena_chunks;
-					const u64 room = early_chunks + (u64)nd * 3 + 4096;
-					int prc = pin_take(c, room * CHUNK_ITEMS * sizeof(Item) + 16, &early);
-					if (prc) {
-						return prc;
-					}
-					if (early_chunks) {
-						HIP_TRY(c, hipMemcpyAsync(early.p, c->arena.p, early_chunks * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sA));
-					}
-				}
-				if (nd > 0 && status == 0) {
-					MachineArgs a2 = ra;
-					a2.ev_list = nullptr;
-					if (const char* dbg = getenv("NTEDIT_HIP_PASS2_DEBUG")) {
-						a2.p.debug_stop = (u32)atoi(dbg); // timing ablations; results are NOT valid
-					}
-					hipEvent_t e0 = c->ev[5];
-					launch_wave_pass(a2, (const u32*)c->deferred.p, nd);
-					HIP_TRY(c, hipGetLastError());
-					HIP_TRY(c, hipEventRecord(c->ev[2], sB));
-					HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
-					HIP_TRY(c, hipStreamSynchronize(sB));
-					status = h_tail[2];
-					float t = 0.f;
-					(void)hipEventElapsedTime(&t, e0, c->ev[2]);
-					p2_ms += t;
-				}
-				return 0;
-			};
-			u32 n_A = n32, n_B = 0, n_C = 0;
-			if (!rounds) {
-				if ((rc = run_round(nullptr, n32, true))) {
-					return bail(rc);
-				}
-			} else {
-				const u32 gap = c->dp.k + 16;
-				auto list_count = [&](u32* out) -> int {
-					HIP_TRY(c, hipMemcpyAsync(out, d_list_n, 4, hipMemcpyDeviceToHost, sB));
-					HIP_TRY(c, hipStreamSynchronize(sB));
-					return 0;
-				};
-				auto prefix_max = [&]() {
-					hipLaunchKernelGGL(k_ev_prefix_max_1, dim3(pm_blocks), dim3(1024), 0, sB, (const u64*)a.ev_cover, n32, d_before, d_bmax);
-					hipLaunchKernelGGL(k_ev_prefix_max_2, dim3(pm_blocks), dim3(1024), 0, sB, n32, d_before, (const u64*)d_bmax);
-				};
-				HIP_BAIL(hipMemsetAsync(d_list_n, 0, 4, sB));
-				hipLaunchKernelGGL(k_ev_primaries, dim3(sel_blocks), dim3(EVR_TPB), 0, sB, (const u64*)d_events, n32, gap, a.ev_flags, d_list, d_list_n);
-				if ((rc = list_count(&n_A)) || (rc = run_round(d_list, n_A, true))) {
-					return bail(rc);
-				}
-				if (status == 0 && n_A < n32) {
-					prefix_max();
-					HIP_BAIL(hipMemsetAsync(d_list_n, 0, 4, sB));
-					hipLaunchKernelGGL(k_ev_select<0>, dim3(sel_blocks), dim3(EVR_TPB), 0, sB, (const u64*)d_events, n32,
-					                   (const u64*)a.ev_cover, (const u64*)d_before, a.ev_flags, d_first, d_list, d_list_n);
-					if ((rc = list_count(&n_B)) || (rc = run_round(d_list, n_B, false))) {
-						return bail(rc);
-					}
-					if (status == 0) {
-						prefix_max();
-						HIP_BAIL(hipMemsetAsync(d_list_n, 0, 4, sB));
-						hipLaunchKernelGGL(k_ev_select<1>, dim3(sel_blocks), dim3(EVR_TPB), 0, sB, (const u64*)d_events, n32,
-						                   (const u64*)a.ev_cover, (const u64*)d_before, a.ev_flags, d_first, d_list, d_list_n);
-						if ((rc = list_count(&n_C))) {
-							return bail(rc);
-						}
-						for (int guard = 0; n_C && status == 0 && guard < 64; guard++) {
-							// (a run of round B reached a primary: its secondaries cannot be taken for overtaken)
-							if ((rc = run_round(d_list, n_C, false))) {
-								return bail(rc);
-							}
-							prefix_max();
-							HIP_BAIL(hipMemsetAsync(d_list_n, 0, 4, sB));
-							hipLaunchKernelGGL(k_ev_select<1>, dim3(sel_blocks), dim3(EVR_TPB), 0, sB, (const u64*)d_events, n32,
-							                   (const u64*)a.ev_cover, (const u64*)d_before, a.ev_flags, d_first, d_list, d_list_n);
-							if ((rc = list_count(&n_C))) {
-								return bail(rc);
-							}
-						}
-					}
-				}
-			}
-			HIP_BAIL(hipGetLastError());
-			u32 h_tail[4] = { 0, 0, 0, 0 };
-			keep_a = a;
-			HIP_BAIL(hipEventRecord(c->ev[4], sB));
-			HIP_BAIL(hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
-			HIP_BAIL(hipStreamSynchronize(sB));
-			if (getenv("NTEDIT_HIP_TRACE")) { fprintf(stderr, "[trace] pass2 done: status %u\n", h_tail[2]); }
+			launch_wave_pass(a2, (const u32*)c->deferred.p, nd);
+			HIP_TRY(c, hipGetLastError());
+			HIP_TRY(c, hipEventRecord(c->ev[2], sB));
+			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+			HIP_TRY(c, hipStreamSynchronize(sB));
 			status = h_tail[2];
-			deferred_total += n_def;
-			skipped_total += rounds ? (u64)n32 - n_A - n_B : 0; // (events round C had to run are few; they stay counted here)
-			float p_all = 0.f;
-			(void)hipEventElapsedTime(&p_all, c->ev[3], c->ev[4]);
-			ms_machine += p_all;
-			if (getenv("NTEDIT_HIP_DEBUG")) {
-				fprintf(
-				    stderr,
-				    "[ntedit_hip] chunk %zu/%zu contigs %u-%u events %llu (round A %u, B %u, C %u; %u skipped as overtaken) sweeps %u "
-				    "machine %.3f ms (sweep launches %.3f ms) arena %u status %u window %u\n",
-				    j + 1, n_ch, ch.c0, ch.c1, (unsigned long long)n_ev, n_A, n_B, n_C, n32 - n_A - n_B - (rounds ? 0 : 0), n_def,
-				    p_all, p2_ms, h_tail[0], status, c->dp.node_window);
-			}
-			if (getenv("NTEDIT_HIP_DEBUG")) {
-				unsigned long long pr[16];
-				machine_wave_profile(pr);
-				if (pr[8]) {
-					fprintf(stderr, "[ntedit_hip] wave-kernel phase cycles/event (n=%llu): seed %llu presence %llu first-miss %llu later-miss %llu advance %llu loop %llu housekeeping %llu flush %llu; positions/event %.1f failing %.1f\n",
-					    pr[8], pr[0] / pr[8], pr[1] / pr[8], pr[2] / pr[8], pr[3] / pr[8], pr[4] / pr[8], pr[5] / pr[8], pr[6] / pr[8], pr[7] / pr[8],
-					    (double)pr[9] / (double)pr[8], (double)pr[10] / (double)pr[8]);
-				}
-			}
-			ev_total += n_ev;
+			float t = 0.f;
+			(void)hipEventElapsedTime(&t, c->ev[5], c->ev[2]);
+			p2_ms += t;
 		}
-		HIP_BAIL(hipStreamSynchronize(sA));
-		HIP_BAIL(hipStreamSynchronize(sB));
-		if (status == 0) {
-			u32 h_tail[4] = { 0, 0, 0, 0 };
-			HIP_BAIL(hipMemcpy(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost));
-			const u64 used_chunks = h_tail[0] < arena_chunks ? h_tail[0] : arena_chunks;
-			r->st.absent_kmers = absent_total;
-			r->st.events = ev_total;
-			r->st.events_deferred = deferred_total;
-			r->arena_items = (size_t)used_chunks * CHUNK_ITEMS;
-			u64 have = 0; // chunks already on the host
-			if (early.p && early.cap >= r->arena_items * sizeof(Item) + 16) {
-				r->arena_buf = early;
-				early.p = nullptr;
-				early.cap = 0;
-				have = early_chunks;
+		return 0;
+	};
+	u32 n_A = n32, n_B = 0, n_C = 0;
+	if (!rounds) {
+		if ((rc = run_round(nullptr, n32, true))) {
+			return rc;
+		}
+	} else {
+		const u32 gap = c->dp.k + 16;
+		auto list_count = [&](u32* out) -> int {
+			HIP_TRY(c, hipMemcpyAsync(out, d_list_n, 4, hipMemcpyDeviceToHost, sB));
+			HIP_TRY(c, hipStreamSynchronize(sB));
+			return 0;
+		};
+		auto prefix_max = [&]() {
+			hipLaunchKernelGGL(k_ev_prefix_max_1, dim3(pm_blocks), dim3(1024), 0, sB, (const u64*)a.ev_cover, n32, d_before, d_bmax);
+			hipLaunchKernelGGL(k_ev_prefix_max_2, dim3(pm_blocks), dim3(1024), 0, sB, n32, d_before, (const u64*)d_bmax);
+		};
+		auto select = [&](int mode, u32* count) -> int {
+			prefix_max();
+			HIP_TRY(c, hipMemsetAsync(d_list_n, 0, 4, sB));
+			if (mode == 0) {
+				hipLaunchKernelGGL(k_ev_select<0>, dim3(sel_blocks), dim3(EVR_TPB), 0, sB, (const u64*)d_events, n32,
+				                   (const u64*)a.ev_cover, (const u64*)d_before, a.ev_flags, d_first, d_list, d_list_n);
 			} else {
-				pin_give(c, early);
-				if ((rc = pin_take(c, r->arena_items * sizeof(Item) + 16, &r->arena_buf))) {
-					return bail(rc);
+				hipLaunchKernelGGL(k_ev_select<1>, dim3(sel_blocks), dim3(EVR_TPB), 0, sB, (const u64*)d_events, n32,
+				                   (const u64*)a.ev_cover, (const u64*)d_before, a.ev_flags, d_first, d_list, d_list_n);
+			}
+			return list_count(count);
+		};
+		HIP_TRY(c, hipMemsetAsync(d_list_n, 0, 4, sB));
+		hipLaunchKernelGGL(k_ev_primaries, dim3(sel_blocks), dim3(EVR_TPB), 0, sB, (const u64*)d_events, n32, gap, a.ev_flags, d_list, d_list_n);
+		if ((rc = list_count(&n_A)) || (rc = run_round(d_list, n_A, true))) {
+			return rc;
+		}
+		if (status == 0 && n_A < n32) {
+			if ((rc = select(0, &n_B)) || (rc = run_round(d_list, n_B, false))) {
+				return rc;
+			}
+			// (a run of round B that reaches a primary: that primary's secondaries cannot be taken for overtaken)
+			u32 n_v = 0;
+			for (int guard = 0; status == 0 && guard < 64; guard++) {
+				if ((rc = select(1, &n_v))) {
+					return rc;
+				}
+				if (n_v == 0) {
+					break;
+				}
+				n_C += n_v;
+				if ((rc = run_round(d_list, n_v, false))) {
+					return rc;
 				}
 			}
-			if ((rc = pin_take(c, ev_total * 4 + 16, &r->first_buf))) {
-				return bail(rc);
-			}
-			if (used_chunks > have) {
-				const size_t off = (size_t)have * CHUNK_ITEMS * sizeof(Item);
-				HIP_BAIL(hipMemcpyAsync((char*)r->arena_buf.p + off, (char*)c->arena.p + off, r->arena_items * sizeof(Item) - off, hipMemcpyDeviceToHost, sB));
-			}
-			if (ev_total) {
-				HIP_BAIL(hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));
-			}
-			HIP_BAIL(hipStreamSynchronize(sB));
-			// Events parked by the budget: decide, in serial order, which of them are applied, re-run
-			// exactly those to completion, carry on behind them (host/resolve.h).  Nothing to do in
-			// the ordinary case.
-			u32 n_unfinished = 0;
-			HIP_BAIL(hipMemcpy(&n_unfinished, (char*)c->counters.p + 52, 4, hipMemcpyDeviceToHost));
-			bool redo = false;
-			if (n_unfinished && n_ch == 1) {
-				nte_host::Resolver rs((const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p, ev_total);
-				std::vector<u32> rerun;
-				if (!rs.start(rerun)) {
-					return bail(fail(c, NTEDIT_E_DEVICE, "malformed event records"));
-				}
-				u64 have_chunks = used_chunks;
-				unsigned rounds = 0;
-				while (!rerun.empty()) {
-					HIP_BAIL(hipMemcpyAsync(c->deferred.p, rerun.data(), rerun.size() * 4, hipMemcpyHostToDevice, sB));
-					MachineArgs ra = keep_a;
-					ra.p.event_budget = 0;
-					launch_wave_pass(ra, (const u32*)c->deferred.p, (u32)rerun.size());
-					HIP_BAIL(hipGetLastError());
-					u32 t2[4] = { 0, 0, 0, 0 };
-					HIP_BAIL(hipMemcpyAsync(t2, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
-					HIP_BAIL(hipStreamSynchronize(sB));
-					if (t2[2]) {
-						status = t2[2];
-						redo = true;
-						break;
-					}
-					const u64 now_chunks = t2[0] < arena_chunks ? t2[0] : arena_chunks;
-					const size_t need = (size_t)now_chunks * CHUNK_ITEMS * sizeof(Item) + 16;
-					if (r->arena_buf.cap < need) {
-						PinBuf bigger;
-						if ((rc = pin_take(c, need + need / 2, &bigger))) {
-							return bail(rc);
-						}
-						memcpy(bigger.p, r->arena_buf.p, (size_t)have_chunks * CHUNK_ITEMS * sizeof(Item));
-						pin_give(c, r->arena_buf);
-						r->arena_buf = bigger;
-					}
-					if (now_chunks > have_chunks) {
-						const size_t off = (size_t)have_chunks * CHUNK_ITEMS * sizeof(Item);
-						HIP_BAIL(hipMemcpyAsync((char*)r->arena_buf.p + off, (char*)c->arena.p + off,
-						                          (size_t)(now_chunks - have_chunks) * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sB));
-					}
-					HIP_BAIL(hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));
-					HIP_BAIL(hipStreamSynchronize(sB));
-					have_chunks = now_chunks;
-					r->arena_items = (size_t)now_chunks * CHUNK_ITEMS;
-					rs.rebind((const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p);
-					rerun.clear();
-					if (!rs.resume(rerun) || ++rounds > 10000000u) {
-						return bail(fail(c, NTEDIT_E_DEVICE, "parked events could not be resolved"));
-					}
-				}
-				if (getenv("NTEDIT_HIP_DEBUG")) {
-					fprintf(stderr, "[ntedit_hip] %u events parked by the budget, %u re-run round(s)\n", n_unfinished, rounds);
-				}
-			}
-			if (redo) {
+		}
+	}
+	HIP_TRY(c, hipGetLastError());
+	keep_a = a;
+	HIP_TRY(c, hipEventRecord(c->ev[4], sB));
+	u32 h_tail[4] = { 0, 0, 0, 0 };
+	HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+	HIP_TRY(c, hipStreamSynchronize(sB));
+	status = h_tail[2];
+	deferred_total += n_def;
+	skipped_total += rounds ? (u64)n32 - n_A - n_B - n_C : 0;
+	float p_all = 0.f;
+	(void)hipEventElapsedTime(&p_all, c->ev[3], c->ev[4]);
+	ms_machine += p_all;
+	if (getenv("NTEDIT_HIP_DEBUG")) {
+		fprintf(
+		    stderr,
+		    "[ntedit_hip] chunk %zu/%zu contigs %u-%u events %llu (round A %u, B %u, C %u; %llu skipped as overtaken) sweeps %u "
+		    "machine %.3f ms (sweep launches %.3f ms) arena %u status %u window %u\n",
+		    j + 1, n_ch, ch.c0, ch.c1, (unsigned long long)n_ev, n_A, n_B, n_C,
+		    (unsigned long long)(rounds ? (u64)n32 - n_A - n_B - n_C : 0), n_def, p_all, p2_ms, h_tail[0], status, c->dp.node_window);
+		unsigned long long pr[16];
+		machine_wave_profile(pr);
+		if (pr[8]) {
+			fprintf(stderr, "[ntedit_hip] wave-kernel phase cycles/event (n=%llu): seed %llu presence %llu first-miss %llu later-miss %llu advance %llu loop %llu housekeeping %llu flush %llu; positions/event %.1f failing %.1f\n",
+			    pr[8], pr[0] / pr[8], pr[1] / pr[8], pr[2] / pr[8], pr[3] / pr[8], pr[4] / pr[8], pr[5] / pr[8], pr[6] / pr[8], pr[7] / pr[8],
+			    (double)pr[9] / (double)pr[8], (double)pr[10] / (double)pr[8]);
+		}
+	}
+	ev_total += n_ev;
+	return 0;
+}
+
+// edit records to the host; *redo = the batch has to be run again with more room
+int
+PolishRun::collect(bool* redo)
+{
+	int rc;
+	*redo = false;
+	u32 h_tail[4] = { 0, 0, 0, 0 };
+	HIP_TRY(c, hipMemcpy(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost));
+	const u64 used_chunks = h_tail[0] < arena_chunks ? h_tail[0] : arena_chunks;
+	r->st.absent_kmers = absent_total;
+	r->st.events = ev_total;
+	r->st.events_deferred = deferred_total;
+	r->arena_items = (size_t)used_chunks * CHUNK_ITEMS;
+	u64 have = 0; // chunks already on the host
+	if (early.p && early.cap >= r->arena_items * sizeof(Item) + 16) {
+		r->arena_buf = early;
+		early.p = nullptr;
+		early.cap = 0;
+		have = early_chunks;
+	} else {
+		pin_give(c, early);
+		if ((rc = pin_take(c, r->arena_items * sizeof(Item) + 16, &r->arena_buf))) {
+			return rc;
+		}
+	}
+	if ((rc = pin_take(c, ev_total * 4 + 16, &r->first_buf))) {
+		return rc;
+	}
+	if (used_chunks > have) {
+		const size_t off = (size_t)have * CHUNK_ITEMS * sizeof(Item);
+		HIP_TRY(c, hipMemcpyAsync((char*)r->arena_buf.p + off, (char*)c->arena.p + off, r->arena_items * sizeof(Item) - off, hipMemcpyDeviceToHost, sB));
+	}
+	if (ev_total) {
+		HIP_TRY(c, hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));
+	}
+	HIP_TRY(c, hipStreamSynchronize(sB));
+	// Events parked by the budget: decide, in serial order, which of them are applied, re-run
+	// exactly those to completion, carry on behind them (host/resolve.h).  Nothing to do in
+	// the ordinary case.
+	u32 n_unfinished = 0;
+	HIP_TRY(c, hipMemcpy(&n_unfinished, (char*)c->counters.p + 52, 4, hipMemcpyDeviceToHost));
+	if (n_unfinished && n_ch == 1) {
+		nte_host::Resolver rs((const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p, ev_total);
+		std::vector<u32> rerun;
+		if (!rs.start(rerun)) {
+			return fail(c, NTEDIT_E_DEVICE, "malformed event records");
+		}
+		u64 have_chunks = used_chunks;
+		unsigned rounds = 0;
+		while (!rerun.empty()) {
+			HIP_TRY(c, hipMemcpyAsync(c->deferred.p, rerun.data(), rerun.size() * 4, hipMemcpyHostToDevice, sB));
+			MachineArgs ra = keep_a;
+			ra.p.event_budget = 0;
+			ra.ev_cover = nullptr; // (the rounds are over)
+			ra.ev_flags = nullptr;
+			launch_wave_pass(ra, (const u32*)c->deferred.p, (u32)rerun.size());
+			HIP_TRY(c, hipGetLastError());
+			u32 t2[4] = { 0, 0, 0, 0 };
+			HIP_TRY(c, hipMemcpyAsync(t2, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+			HIP_TRY(c, hipStreamSynchronize(sB));
+			if (t2[2]) {
 				// a re-run ran out of arena / rope window: the whole batch again, with more room
+				status = t2[2];
+				*redo = true;
 				pin_give(c, r->arena_buf);
 				pin_give(c, r->first_buf);
-			} else {
-			HIP_BAIL(hipEventRecord(c->ev[4], sB));
-			HIP_BAIL(hipStreamSynchronize(sB));
-			// one entry per event, in position order; NONE32 = the event produced nothing (the
-			// renderer skips those)
-			r->n_ev_first = ev_total;
-			// timings: screening = sum of its launches (they may overlap machine kernels)
-			float ms_screen = 0.f;
-			const size_t n_scr = pipelined ? n_ch : 1;
-			for (size_t j = 0; j < n_scr; j++) {
-				float t = 0.f;
-				(void)hipEventElapsedTime(&t, c->chunk_ev[2 * j], c->chunk_ev[2 * j + 1]);
-				ms_screen += t;
+				return 0;
 			}
-			r->st.ms_screen = ms_screen;
-			r->st.screen_launches = h2d_launches ? h2d_launches : (uint32_t)n_scr;
-			if (!pipelined && !h2d_launches && c->bin_chunks_last) {
-				r->st.screen_binned = 1;
-				r->st.screen_launches = c->bin_chunks_last;
-				for (u32 q = 0; q < c->bin_chunks_last; q++) {
-					float tp = 0.f, tq = 0.f;
-					(void)hipEventElapsedTime(&tp, c->bin_ev[3 * q], c->bin_ev[3 * q + 1]);
-					(void)hipEventElapsedTime(&tq, c->bin_ev[3 * q + 1], c->bin_ev[3 * q + 2]);
-					r->st.ms_partition += tp;
-					r->st.ms_probe += tq;
+			const u64 now_chunks = t2[0] < arena_chunks ? t2[0] : arena_chunks;
+			const size_t need = (size_t)now_chunks * CHUNK_ITEMS * sizeof(Item) + 16;
+			if (r->arena_buf.cap < need) {
+				PinBuf bigger;
+				if ((rc = pin_take(c, need + need / 2, &bigger))) {
+					return rc;
 				}
+				memcpy(bigger.p, r->arena_buf.p, (size_t)have_chunks * CHUNK_ITEMS * sizeof(Item));
+				pin_give(c, r->arena_buf);
+				r->arena_buf = bigger;
 			}
-			r->st.events_skipped = (uint32_t)skipped_total;
-			r->st.ms_machine = ms_machine;
-			(void)ms_extract;
-			r->st.ms_extract = 0.f;
-			HIP_BAIL(hipEventElapsedTime(&r->st.ms_total, c->ev[0], c->ev[4]));
-			c->last_ms = ms_screen;
-			break;
+			if (now_chunks > have_chunks) {
+				const size_t off = (size_t)have_chunks * CHUNK_ITEMS * sizeof(Item);
+				HIP_TRY(c, hipMemcpyAsync((char*)r->arena_buf.p + off, (char*)c->arena.p + off,
+				                          (size_t)(now_chunks - have_chunks) * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sB));
+			}
+			HIP_TRY(c, hipMemcpyAsync(r->first_buf.p, c->first_chunk.p, ev_total * 4, hipMemcpyDeviceToHost, sB));
+			HIP_TRY(c, hipStreamSynchronize(sB));
+			have_chunks = now_chunks;
+			r->arena_items = (size_t)now_chunks * CHUNK_ITEMS;
+			rs.rebind((const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p);
+			rerun.clear();
+			if (!rs.resume(rerun) || ++rounds > 10000000u) {
+				return fail(c, NTEDIT_E_DEVICE, "parked events could not be resolved");
 			}
 		}
-		if (attempt >= 4) {
-			return bail(fail(c, NTEDIT_E_OVERFLOW, "event machine ran out of room (status %u)", status));
-		}
-		if (status & EV_ARENA_FULL) {
-			arena_chunks *= 4;
-		}
-		if (status & EV_OVERFLOW) {
-			c->dp.node_window *= 2;
+		if (getenv("NTEDIT_HIP_DEBUG")) {
+			fprintf(stderr, "[ntedit_hip] %u events parked by the budget, %u re-run round(s)\n", n_unfinished, rounds);
 		}
 	}
 	return 0;
-#undef HIP_BAIL
 }
+
+int
+PolishRun::finish()
+{
+	HIP_TRY(c, hipEventRecord(c->ev[4], sB));
+	HIP_TRY(c, hipStreamSynchronize(sB));
+	// one entry per event, in position order; NONE32 = the event produced nothing (the renderer skips those)
+	r->n_ev_first = ev_total;
+	// timings: screening = sum of its launches (they may overlap machine kernels)
+	float ms_screen = 0.f;
+	const size_t n_scr = pipelined ? n_ch : 1;
+	for (size_t j = 0; j < n_scr; j++) {
+		float t = 0.f;
+		(void)hipEventElapsedTime(&t, c->chunk_ev[2 * j], c->chunk_ev[2 * j + 1]);
+		ms_screen += t;
+	}
+	r->st.ms_screen = ms_screen;
+	r->st.screen_launches = h2d_launches ? h2d_launches : (uint32_t)n_scr;
+	if (!pipelined && !h2d_launches && c->bin_chunks_last) {
+		r->st.screen_binned = 1;
+		r->st.screen_launches = c->bin_chunks_last;
+		for (u32 q = 0; q < c->bin_chunks_last; q++) {
+			float tp = 0.f, tq = 0.f;
+			(void)hipEventElapsedTime(&tp, c->bin_ev[3 * q], c->bin_ev[3 * q + 1]);
+			(void)hipEventElapsedTime(&tq, c->bin_ev[3 * q + 1], c->bin_ev[3 * q + 2]);
+			r->st.ms_partition += tp;
+			r->st.ms_probe += tq;
+		}
+	}
+	r->st.events_skipped = (uint32_t)skipped_total;
+	r->st.ms_machine = ms_machine;
+	r->st.ms_extract = 0.f;
+	HIP_TRY(c, hipEventElapsedTime(&r->st.ms_total, c->ev[0], c->ev[4]));
+	c->last_ms = ms_screen;
+	return 0;
+}
+
+} // namespace
+
+extern "C" int
+ntedit_hip_polish_batch(
+    ntedit_hip_ctx* c,
+    const char* bases,
+    uint64_t n,
+    const uint64_t* offsets,
+    const uint32_t* lens,
+    uint32_t n_contigs,
+    int on_device,
+    ntedit_hip_result** out)
+{
+	if (!c || !out || (n && !bases) || (n_contigs && (!offsets || !lens))) {
+		return fail(c, NTEDIT_E_ARG, "polish_batch: bad argument");
+	}
+	*out = nullptr;
+	HIP_TRY(c, hipSetDevice(c->device));
+	int rc = refresh_params(c);
+	if (rc) {
+		return rc;
+	}
+	for (u32 i = 0; i < n_contigs; i++) {
+		if (offsets[i] + lens[i] > n || (i + 1 < n_contigs && offsets[i] + lens[i] >= offsets[i + 1])) {
+			return fail(c, NTEDIT_E_ARG, "polish_batch: contig %u breaks the batch layout", i);
+		}
+	}
+	ntedit_hip_result* r = new ntedit_hip_result();
+	r->owner = c;
+	memset(&r->st, 0, sizeof r->st);
+	r->st.bases = n;
+	r->snv = c->hp.snv ? 1 : 0;
+	if (n == 0 || n_contigs == 0) {
+		*out = r;
+		return 0;
+	}
+	PolishRun run;
+	run.c = c;
+	run.bases = bases;
+	run.n = n;
+	run.offsets = offsets;
+	run.lens = lens;
+	run.n_contigs = n_contigs;
+	run.on_device = on_device;
+	run.r = r;
+	if ((rc = run.plan())) {
+		return run.bail(rc);
+	}
+	for (int attempt = 0;; attempt++) {
+		if ((rc = run.begin_attempt()) || (rc = run.launch_screening(attempt))) {
+			return run.bail(rc);
+		}
+		for (size_t j = 0; j < run.n_ch && run.status == 0; j++) {
+			if ((rc = run.run_chunk_events(j))) {
+				return run.bail(rc);
+			}
+		}
+		if (hipStreamSynchronize(run.sA) != hipSuccess || hipStreamSynchronize(run.sB) != hipSuccess) {
+			return run.bail(fail(c, NTEDIT_E_DEVICE, "stream synchronisation failed: %s", hipGetErrorString(hipGetLastError())));
+		}
+		if (run.status == 0) {
+			bool redo = false;
+			if ((rc = run.collect(&redo))) {
+				return run.bail(rc);
+			}
+			if (!redo) {
+				if ((rc = run.finish())) {
+					return run.bail(rc);
+				}
+				break;
+			}
+		}
+		if (attempt >= 4) {
+			return run.bail(fail(c, NTEDIT_E_OVERFLOW, "event machine ran out of room (status %u)", run.status));
+		}
+		if (run.status & EV_ARENA_FULL) {
+			run.arena_chunks *= 4;
+		}
+		if (run.status & EV_OVERFLOW) {
+			c->dp.node_window *= 2;
+		}
+	}
+	*out = r;
+	return 0;
+}
+
+extern "C" {
 
 void
 ntedit_hip_result_free(ntedit_hip_result* r)

@@ -13,6 +13,7 @@
 // the reference).
 #include "../../include/ntedit_hip.h"
 #include "fasta.h"
+#include "fasta_map.h"
 
 #include <algorithm>
 #include <chrono>
@@ -75,7 +76,8 @@ enum
 	OPT_SHARD,
 	OPT_REPORT,
 	OPT_START_GRID,
-	OPT_EVENT_BUDGET
+	OPT_EVENT_BUDGET,
+	OPT_NO_MAP
 };
 static const struct option longopts[] = {
 	{ "threads", required_argument, nullptr, 't' },
@@ -105,6 +107,7 @@ static const struct option longopts[] = {
 	{ "start-grid", required_argument, nullptr, OPT_START_GRID },     // tuning / tests: ntedit_hip_params.start_grid
 	{ "event-budget", required_argument, nullptr, OPT_EVENT_BUDGET }, // tuning / tests: ntedit_hip_params.event_budget
 	{ "shard", required_argument, nullptr, OPT_SHARD },
+	{ "no-map", no_argument, nullptr, OPT_NO_MAP }, // tests: plain FASTA through the streaming reader as well
 	{ "report", no_argument, nullptr, OPT_REPORT },
 	{ "help", no_argument, nullptr, OPT_HELP },
 	{ "version", no_argument, nullptr, OPT_VERSION },
@@ -142,7 +145,41 @@ parse(int c, const char* arg, T& out)
 
 struct Batch
 {
-	std::string blob;
+	std::string blob; // filled by the streaming reader (append per line) ...
+	char* raw = nullptr; // ... or by the mapped reader (whole records copied concurrently; never zero-filled)
+	size_t raw_n = 0, raw_cap = 0;
+	const char* data() const { return raw_n ? raw : blob.data(); }
+	size_t size() const { return raw_n ? raw_n : blob.size(); }
+	bool raw_pinned = false; // raw came from ntedit_hip_host_alloc (page-locked: asynchronous H2D at link speed)
+	void release_raw()
+	{
+		if (raw_pinned) {
+			ntedit_hip_host_free(raw);
+		} else {
+			free(raw);
+		}
+		raw = nullptr;
+		raw_cap = 0;
+		raw_pinned = false;
+	}
+	bool reserve_raw(size_t n)
+	{
+		if (n > raw_cap) {
+			release_raw();
+			raw_cap = n + n / 8 + (1u << 20);
+			raw = (char*)malloc(raw_cap);
+			if (raw) {
+				const uintptr_t lo = ((uintptr_t)raw + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+				const uintptr_t hi = ((uintptr_t)raw + raw_cap) & ~(uintptr_t)((2u << 20) - 1);
+				if (hi > lo) {
+					(void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
+				}
+			} else {
+				raw_cap = 0;
+			}
+		}
+		return raw != nullptr;
+	}
 	std::vector<uint64_t> offs;
 	std::vector<uint32_t> lens;
 	std::vector<std::string> names;
@@ -150,6 +187,7 @@ struct Batch
 	void clear()
 	{
 		blob.clear();
+		raw_n = 0;
 		offs.clear();
 		lens.clear();
 		names.clear();
@@ -201,7 +239,7 @@ main(int argc, char** argv)
 	int verbose = 0, gpu = 0, report = 0;
 	unsigned long long batch_bases = 1ull << 30;
 	unsigned shard_i = 0, shard_n = 1;
-	bool die = false;
+	bool die = false, no_map = false;
 	for (int c; (c = getopt_long(argc, argv, shortopts, longopts, nullptr)) != -1;) {
 		switch (c) {
 		case '?':
@@ -296,6 +334,9 @@ main(int argc, char** argv)
 		case OPT_REPORT:
 			report = 1;
 			break;
+		case OPT_NO_MAP:
+			no_map = true;
+			break;
 		case OPT_HELP:
 			fputs(USAGE, stderr);
 			exit(EXIT_SUCCESS);
@@ -339,11 +380,22 @@ main(int argc, char** argv)
 		fprintf(stderr, PROGRAM ": error: no usable HIP device %d (this build has no CPU path).\n", gpu);
 		exit(EXIT_FAILURE);
 	}
+	// (Page-locking the batch buffers was tried: 3 x 1.07 GiB cost 1.3 s of process time for 0.07 s less in the
+	// polish_batch calls of a 3 Gbp draft, and end to end the renderer is the critical path anyway.  Batches are
+	// ordinary memory; the runtime stages their pieces.)
+	Work pool[3];
+	std::thread pin_helper; // (kept: nothing to join)
+	auto fatal = [&]() {
+		if (pin_helper.joinable()) {
+			pin_helper.join(); // (never leave the process while the helper is inside the HIP runtime)
+		}
+		exit(EXIT_FAILURE);
+	};
 	time(&rawtime);
 	printf("---------- loading Bloom filter from file           : %s\n", ctime(&rawtime));
 	if (ntedit_hip_load_filter_file(ctx, NTEDIT_FILTER_PRIMARY, bf.c_str()) != 0) {
 		fprintf(stderr, PROGRAM ": error: Bloom filter file supplied (-r) is incorrect. (%s)\n", ntedit_hip_last_error(ctx));
-		exit(EXIT_FAILURE);
+		fatal();
 	}
 	uint32_t k = 0, h = 0;
 	uint64_t nbytes = 0;
@@ -389,18 +441,18 @@ main(int argc, char** argv)
 		printf("---------- loading secondary Bloom filter from file : %s\n", ctime(&rawtime));
 		if (ntedit_hip_load_filter_file(ctx, NTEDIT_FILTER_SECONDARY, bfrep.c_str()) != 0) {
 			fprintf(stderr, PROGRAM ": error: secondary Bloom filter file supplied (-e) is incorrect.\n");
-			exit(EXIT_FAILURE);
+			fatal();
 		}
 		uint32_t k2 = 0;
 		ntedit_hip_filter_info(ctx, NTEDIT_FILTER_SECONDARY, &k2, nullptr, nullptr, nullptr);
 		if (k2 != k) {
 			fprintf(stderr, PROGRAM ": error: secondary Bloom filter k size (%u) is different than main Bloom filter k size (%u)\n", k2, k);
-			exit(EXIT_FAILURE);
+			fatal();
 		}
 	}
 	if (ntedit_hip_set_params(ctx, &p) != 0) {
 		fprintf(stderr, PROGRAM ": error: %s\n", ntedit_hip_last_error(ctx));
-		exit(EXIT_FAILURE);
+		fatal();
 	}
 
 	time(&rawtime);
@@ -411,17 +463,17 @@ main(int argc, char** argv)
 		FILE* f = fopen(fa_path.c_str(), "wb");
 		if (!f) {
 			fprintf(stderr, PROGRAM ": error: cannot write `%s'\n", fa_path.c_str());
-			exit(EXIT_FAILURE);
+			fatal();
 		}
 		fclose(f);
 	}
 	if (ntedit_hip_write_tsv_header(tsv_path.c_str(), k, p.jump, counting) != 0) {
 		fprintf(stderr, PROGRAM ": error: cannot write `%s'\n", tsv_path.c_str());
-		exit(EXIT_FAILURE);
+		fatal();
 	}
 	if (ntedit_hip_write_vcf_header(vcf_path.c_str(), draft.c_str()) != 0) { // ntedit.cpp:2192-2211
 		fprintf(stderr, PROGRAM ": error: cannot write `%s'\n", vcf_path.c_str());
-		exit(EXIT_FAILURE);
+		fatal();
 	}
 	ntedit_hip_annot* annot = nullptr;
 	if (!vcf.empty()) {
@@ -432,24 +484,44 @@ main(int argc, char** argv)
 		}
 	}
 
+	// Plain multi-FASTA files are taken apart by several threads from a mapping of the file (fasta_map.h); anything
+	// else (gzip, FASTQ, CR line ends, ...) goes through the streaming reader.  --no-map forces the latter.
+	unsigned ingest_threads = threads_given ? nthreads : std::thread::hardware_concurrency();
+	if (ingest_threads > 16) {
+		ingest_threads = 16;
+	}
+	if (ingest_threads < 1) {
+		ingest_threads = 1;
+	}
+	nte_host::FastaMap fmap(no_map ? "" : draft.c_str(), ingest_threads);
+
 	// --shard I/N: the contigs >= -z are split by bases, greedy longest-first (the partition of
 	// ntedit_amd.dist.shard_contigs): a first pass over the draft collects the lengths
 	std::vector<uint8_t> mine; // by ordinal
 	if (shard_n > 1) {
-		nte_host::FastaReader scan(draft.c_str());
-		if (!scan.ok()) {
-			fprintf(stderr, PROGRAM ": error: `%s': cannot open\n", draft.c_str());
-			exit(EXIT_FAILURE);
-		}
 		std::vector<uint64_t> lens;
-		std::string h, sq;
-		while (scan.next(h, sq)) {
-			const void* z = memchr(sq.data(), 0, sq.size());
-			const size_t len = z ? (size_t)((const char*)z - sq.data()) : sq.size();
-			if (len >= p.min_contig_len) {
-				lens.push_back(len);
+		if (fmap.ok()) {
+			fmap.measure(0, fmap.records());
+			for (size_t i = 0; i < fmap.records(); i++) {
+				if (fmap.length(i) >= p.min_contig_len) {
+					lens.push_back(fmap.length(i));
+				}
 			}
-			sq.clear();
+		} else {
+			nte_host::FastaReader scan(draft.c_str());
+			if (!scan.ok()) {
+				fprintf(stderr, PROGRAM ": error: `%s': cannot open\n", draft.c_str());
+				fatal();
+			}
+			std::string h, sq;
+			while (scan.next(h, sq)) {
+				const void* z = memchr(sq.data(), 0, sq.size());
+				const size_t len = z ? (size_t)((const char*)z - sq.data()) : sq.size();
+				if (len >= p.min_contig_len) {
+					lens.push_back(len);
+				}
+				sq.clear();
+			}
 		}
 		std::vector<uint32_t> order(lens.size());
 		for (size_t i = 0; i < order.size(); i++) {
@@ -472,14 +544,14 @@ main(int argc, char** argv)
 	nte_host::FastaReader reader(draft.c_str());
 	if (!reader.ok()) {
 		fprintf(stderr, PROGRAM ": error: `%s': cannot open\n", draft.c_str());
-		exit(EXIT_FAILURE);
+		fatal();
 	}
 	FILE* index_f = nullptr;
 	if (shard_n > 1) {
 		index_f = fopen((prefix + ".index.tsv").c_str(), "wb");
 		if (!index_f) {
 			fprintf(stderr, PROGRAM ": error: cannot write `%s.index.tsv'\n", prefix.c_str());
-			exit(EXIT_FAILURE);
+			fatal();
 		}
 		fprintf(index_f, "#shard %u/%u\tordinal\tfa_bytes\ttsv_bytes\tvcf_bytes\n", shard_i, shard_n);
 	}
@@ -495,8 +567,10 @@ main(int argc, char** argv)
 	// Three stages, one batch each at a time: this thread's reader helper parses the draft
 	// into batch N+1 while the GPU polishes batch N and the writer renders batch N-1.
 	// Output order = input order (the reference at -t 1).
-	Work pool[3];
 	Channel free_q, gpu_q, write_q;
+	if (pin_helper.joinable()) {
+		pin_helper.join();
+	}
 	for (Work& w : pool) {
 		free_q.push(&w);
 	}
@@ -521,6 +595,80 @@ main(int argc, char** argv)
 			w = next;
 			tr0 = std::chrono::steady_clock::now();
 		};
+		if (fmap.ok()) {
+			// ---- mapped reader: pick the records of a batch, measure / copy them concurrently
+			const size_t N = fmap.records();
+			size_t i = 0;
+			std::vector<size_t> pick;
+			std::vector<char*> dst;
+			const size_t GROUP = 1024;
+			size_t measured = 0;
+			while (i < N) {
+				Batch& b = w->b;
+				pick.clear();
+				size_t total = 0;
+				while (i < N) {
+					if (i >= measured) {
+						const size_t cnt = N - measured < GROUP ? N - measured : GROUP;
+						fmap.measure(measured, cnt);
+						measured += cnt;
+					}
+					const uint64_t len = fmap.length(i);
+					bool keep = false;
+					if (len >= p.min_contig_len) { // ntedit.cpp:2242
+						keep = shard_n == 1 || (idx < mine.size() && mine[idx]);
+					}
+					if (keep) {
+						if (len > 0xFFFFFFF0ull) {
+							fprintf(stderr, PROGRAM ": error: contig longer than 2^32 bases\n");
+							fflush(nullptr);
+							_exit(EXIT_FAILURE);
+						}
+						if (!pick.empty() && total + len + 1 > batch_bases) {
+							break; // the batch is full: this contig opens the next one
+						}
+						b.offs.push_back(total);
+						b.lens.push_back((uint32_t)len);
+						b.names.push_back(fmap.header(i));
+						b.ordinals.push_back(idx);
+						pick.push_back(i);
+						total += len + 1;
+						total_bases += len;
+					}
+					if (len >= p.min_contig_len) {
+						idx++;
+					}
+					n_contigs++;
+					if (n_contigs % 1000000 == 0) {
+						printf("Processed %llu\n", n_contigs);
+					}
+					i++;
+				}
+				if (!pick.empty()) {
+					if (!b.reserve_raw(total)) {
+						fprintf(stderr, PROGRAM ": error: out of memory for a batch of %zu bytes\n", total);
+						fflush(nullptr);
+						_exit(EXIT_FAILURE);
+					}
+					dst.resize(pick.size());
+					for (size_t q = 0; q < pick.size(); q++) {
+						dst[q] = b.raw + b.offs[q];
+						b.raw[b.offs[q] + b.lens[q]] = '\n';
+					}
+					fmap.copy(pick.data(), dst.data(), pick.size());
+					b.raw_n = total;
+				}
+				if (i < N) {
+					s_read += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+					Work* nx = free_q.pop();
+					tr0 = std::chrono::steady_clock::now();
+					hand_over(nx);
+				}
+			}
+			hand_over(nullptr);
+			gpu_q.push(nullptr);
+			return;
+		}
 		for (;;) {
 			Batch& b = w->b;
 			const size_t before = b.blob.size();
@@ -597,7 +745,7 @@ main(int argc, char** argv)
 				sizes.assign(names.size() * 3 + 3, 0);
 				wo.out_sizes = sizes.data();
 			}
-			int rc = ntedit_hip_write_outputs_ex(w->res, b.blob.data(), b.offs.data(), b.lens.data(), names.data(),
+			int rc = ntedit_hip_write_outputs_ex(w->res, b.data(), b.offs.data(), b.lens.data(), names.data(),
 			                                     (uint32_t)names.size(), &wo);
 			if (rc != 0) {
 				fprintf(stderr, PROGRAM ": error: cannot write outputs\n");
@@ -635,7 +783,7 @@ main(int argc, char** argv)
 			continue;
 		}
 		auto tc0 = std::chrono::steady_clock::now();
-		int rc = ntedit_hip_polish_batch(ctx, b.blob.data(), b.blob.size(), b.offs.data(), b.lens.data(),
+		int rc = ntedit_hip_polish_batch(ctx, b.data(), b.size(), b.offs.data(), b.lens.data(),
 		                                 (uint32_t)b.names.size(), 0, &w->res);
 		if (rc != 0) {
 			fprintf(stderr, PROGRAM ": error: %s\n", ntedit_hip_last_error(ctx));
@@ -670,6 +818,9 @@ main(int argc, char** argv)
 		       (unsigned long long)tot.events_applied, (unsigned long long)tot.absent_kmers,
 		       (unsigned long long)tot.substitutions, (unsigned long long)tot.insertions,
 		       (unsigned long long)tot.deletions);
+	}
+	for (Work& w : pool) {
+		w.b.release_raw();
 	}
 	ntedit_hip_annot_free(annot);
 	ntedit_hip_destroy(ctx);

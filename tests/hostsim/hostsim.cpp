@@ -387,3 +387,45 @@ hostsim_fasta_dump(const char* in_path, const char* out_path)
 	fclose(o);
 	return n;
 }
+
+// TEST-ONLY: the same dump through the mapped, multi-threaded reader (ntedit_amd/host/fasta_map.cpp);
+// -1 when it refuses the file (then the streaming reader is the one that parses it)
+#include "../../ntedit_amd/host/fasta_map.h"
+extern "C" int
+hostsim_fasta_map_dump(const char* in_path, const char* out_path, unsigned threads)
+{
+	nte_host::FastaMap m(in_path, threads);
+	if (!m.ok()) {
+		return -1;
+	}
+	FILE* o = fopen(out_path, "wb");
+	if (!o) {
+		return -2;
+	}
+	m.measure(0, m.records());
+	std::vector<size_t> idx(m.records());
+	std::vector<std::string> seqs(m.records());
+	std::vector<char*> dst(m.records());
+	for (size_t i = 0; i < m.records(); i++) {
+		idx[i] = i;
+		seqs[i].resize(m.length(i));
+		dst[i] = seqs[i].empty() ? nullptr : &seqs[i][0];
+	}
+	std::vector<char> dummy(1);
+	for (auto& d : dst) {
+		if (!d) {
+			d = dummy.data();
+		}
+	}
+	m.copy(idx.data(), dst.data(), idx.size());
+	for (size_t i = 0; i < m.records(); i++) {
+		const std::string hdr = m.header(i);
+		fprintf(o, "%zu %zu\n", hdr.size(), seqs[i].size());
+		fwrite(hdr.data(), 1, hdr.size(), o);
+		fputc('\n', o);
+		fwrite(seqs[i].data(), 1, seqs[i].size(), o);
+		fputc('\n', o);
+	}
+	fclose(o);
+	return (int)m.records();
+}

@@ -178,3 +178,86 @@ def test_reader_fuzz(tmp_path):
         with open(p, "wb") as f:
             f.write(data)
         assert dump(p, tmp_path) == model(data), data
+
+
+def map_dump(path, tmp_path, threads):
+    """the mapped, multi-threaded reader (ntedit_amd/host/fasta_map.cpp); None when it refuses the file"""
+    lib = H.hostsim_lib()
+    out = str(tmp_path / "mdump.bin")
+    rc = lib.hostsim_fasta_map_dump(ctypes.c_char_p(path.encode()), ctypes.c_char_p(out.encode()), ctypes.c_uint(threads))
+    if rc == -1:
+        return None
+    assert rc >= 0
+    recs = []
+    with open(out, "rb") as f:
+        while True:
+            line = f.readline()
+            if not line:
+                break
+            hl, sl = map(int, line.split())
+            hdr = f.read(hl)
+            assert f.read(1) == b"\n"
+            seq = f.read(sl)
+            assert f.read(1) == b"\n"
+            recs.append((hdr, seq))
+    assert len(recs) == rc
+    return recs
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_mapped_reader_cases(tmp_path, ci):
+    """whatever the mapped reader accepts it parses like kseq; CR line ends, FASTQ, NUL bytes, leading text and
+    empty files are refused (the streaming reader takes those)"""
+    p = str(tmp_path / "in.fa")
+    with open(p, "wb") as f:
+        f.write(CASES[ci])
+    for threads in (1, 3):
+        got = map_dump(p, tmp_path, threads)
+        if got is not None:
+            assert got == model(CASES[ci])
+    accepted = map_dump(p, tmp_path, 1) is not None
+    assert accepted == (ci in (0, 4, 8, 9)), ci  # 4: '>' '@' '+' inside a line are ordinary characters
+
+
+def test_mapped_reader_large_and_refusals(tmp_path):
+    rng = np.random.default_rng(6)
+    parts = []
+    for i in range(60):
+        n = int(rng.integers(0, 300000))
+        s = bytes(rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), n))
+        w = int(rng.integers(1, 200)) if i % 5 else max(1, n)
+        hdr = b">c%d" % i if i % 3 else b">c%d  len=%d\tx y" % (i, n)
+        body = b"\n".join(s[j:j + w] for j in range(0, n, w))
+        parts.append(hdr + b"\n" + body + (b"\n\n" if i % 7 == 0 else b"\n"))
+    data = b"".join(parts)[:-1]  # (no newline at the very end)
+    p = str(tmp_path / "in.fa")
+    with open(p, "wb") as f:
+        f.write(data)
+    want = model(data)
+    assert dump(p, tmp_path) == want
+    for threads in (1, 2, 7, 16):
+        assert map_dump(p, tmp_path, threads) == want, threads
+    with gzip.open(p + ".gz", "wb", compresslevel=1) as f:
+        f.write(data)
+    assert map_dump(p + ".gz", tmp_path, 4) is None
+    for bad in (data.replace(b"\n", b"\r\n", 3), b"x" + data, data + b"\n@r\nAC\n+\nII\n", data[:1000] + b"\0" + data[1000:]):
+        with open(p, "wb") as f:
+            f.write(bad)
+        assert map_dump(p, tmp_path, 4) is None
+
+
+def test_mapped_reader_fuzz(tmp_path):
+    rng = np.random.default_rng(12)
+    alphabet = np.frombuffer(b">>\n\n\n \tACGTacgtN@+", dtype=np.uint8)
+    p = str(tmp_path / "in.fa")
+    n_acc = 0
+    for it in range(400):
+        n = int(rng.integers(0, 150))
+        data = b">" + bytes(rng.choice(alphabet, n))
+        with open(p, "wb") as f:
+            f.write(data)
+        got = map_dump(p, tmp_path, int(rng.integers(1, 5)))
+        if got is not None:
+            n_acc += 1
+            assert got == model(data), data
+    assert n_acc > 100

@@ -531,3 +531,20 @@ def test_cli_edge_inputs(tmp_path, oracle_build):
             for suf in ("_changes.tsv", "_edited.fa"):
                 assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("g" + suf)), shallow=False), (name, z, suf)
             assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "g_variants.vcf")), (name, z)
+
+
+def test_cli_mapped_reader_equals_streaming(tmp_path, oracle_build):
+    """plain multi-FASTA drafts are ingested by the mapped, multi-threaded reader (several batches, -t threads);
+    the outputs are the streaming reader's (--no-map) and the oracle's, byte for byte"""
+    import subprocess
+    cli = os.path.join(H.ROOT, "ntedit_amd", "ntedit")
+    case = H.make_many_case(str(tmp_path), n_contigs=1500, mean_len=700, seed=13)
+    hp = H.default_params(min_contig_len=200)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"))
+    for tag, extra in (("m", ["-t", "5"]), ("s", ["--no-map"]), ("m1", ["-t", "1", "--batch-bases", "100000"])):
+        r = subprocess.run([cli, "-f", case["draft"], "-r", case["bf"], "-b", str(tmp_path / tag), "-z", "200",
+                            "--batch-bases", "150000"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for suf in ("_changes.tsv", "_edited.fa"):
+            assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / (tag + suf)), shallow=False), (tag, suf)
+        assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / (tag + "_variants.vcf"))), tag

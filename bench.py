@@ -186,7 +186,7 @@ def measured_regions(job, pol, args):
         for _ in range(2):
             t0 = time.perf_counter()
             r = subprocess.run([cli, "-f", draft, "-r", bf, "-b", os.path.join(work, "out"), "--report"],
-                               capture_output=True, text=True)
+                               capture_output=True, text=True, timeout=300)
             wall = time.perf_counter() - t0
             if r.returncode != 0:
                 raise RuntimeError(r.stderr[-500:])

@@ -308,7 +308,9 @@ k_bin_probe(
 #pragma unroll
 			for (int q = 0; q < 4; q++) {
 				const u64 i = i0 + (u64)q * PROBE_TPB + threadIdx.x;
-				rec[q] = i < hi ? records[i] : ~0ULL;
+								// (non-temporal: the records are read once; the slice they probe should keep the XCD's L2 --
+				// 63.6 instead of 67.7 ms per 3 Gbp)
+				rec[q] = i < hi ? __builtin_nontemporal_load(records + i) : ~0ULL;
 			}
 #pragma unroll
 			for (int q = 0; q < 4; q++) {

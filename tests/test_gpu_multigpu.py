@@ -247,3 +247,32 @@ def test_cli_shards_by_bases_and_merge(tmp_path, oracle_build):
     assert max(loads) - min(loads) < 0.1 * sum(loads)
     assert merge_cli_shards(str(tmp_path / "m"), [str(tmp_path / ("s%d" % i)) for i in range(n)]) == len(kept)
     _same_outputs(str(tmp_path / "o"), str(tmp_path / "m"))
+
+
+@pytest.mark.parametrize("bfbytes", [1 << 15, 1 << 16])
+def test_segments_with_an_overloaded_filter(tmp_path, bfbytes, oracle_build):
+    """a filter loaded to a false-positive rate of tens of percent: edit chains run through the stretches the
+    planner takes for clean, and the serial run of a contig can end long before the contig does (the main loop
+    stops when roll() fails, ntedit.cpp:1216-1247) -- every later cut of that contig is then rejected and the
+    segments are polished again joined, up to the contig's end; the result is still byte-identical"""
+    case = H.make_case(str(tmp_path), 8600, contigs=2, n=70000, bfbytes=bfbytes, p_sub=5e-3, p_ins=8e-4, p_del=8e-4)
+    H.run_oracle(case["draft"], case["bf"], H.default_params(), str(tmp_path / "o"))
+    stats = _hip_backend_two_ranks(tmp_path, case, {}, 6000)
+    _same_outputs(str(tmp_path / "o"), str(tmp_path / "g"))
+    assert sum(s[1] for s in stats) >= 6
+
+
+def test_overloaded_filter_300mbp_every_contig(tmp_path, oracle_build, capsys):
+    """300 Mbp against a filter loaded to a false-positive rate of 4 % (the bench's load is 1.2 %): events parked by
+    the budget, edit chains, contigs whose serial run ends early -- every contig byte-identical to the oracle"""
+    import ntedit_amd
+    from ntedit_amd.synth import SyntheticJob
+    import test_gpu_parity as T
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.set_params(ntedit_amd.default_params())
+        job = SyntheticJob(pol, 3e8, k=25, hash_num=3, filter_bytes=1 << 28)
+        st, host, names = T._compare_every_contig(pol, job, tmp_path, "fpr4", capsys)
+        assert st.substitutions > 1000
+    finally:
+        pol.close()

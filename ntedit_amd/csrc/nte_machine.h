@@ -2162,30 +2162,54 @@ struct Machine
 					break;
 				}
 			}
-			// Behind a substitution the next k-1 k-mers hold the new base; they were probed together
-			// (look-ahead) and, as a rule, are all there: the reference rolls through them one position
-			// at a time doing nothing.  With the rope untouched (one position node, cursors k-1 apart)
-			// that stretch of the walk is a pure function of the draft window, so it is taken in one
-			// stride: land on the last position that is looked-ahead, present and still dirty.
-			if (!missing && !rope_touched && la_i < la_n && last_sub_pos >= (int64_t)h_seq_i) {
+			// Behind an edit the next k-1 k-mers hold the new base(s); they were probed together (look-ahead)
+			// and, as a rule, are all there: the reference rolls through them one position at a time doing
+			// nothing.  That stretch of the walk is taken in one stride: the cursors are rolled without reading
+			// characters (increment() only: rope nodes, no draft bytes), as long as the next position is
+			// looked-ahead, present, inside the contig and still dirty -- where the machine would be clean the
+			// main loop has to consult the screening bitmap itself -- and the hash is rolled from the window codes
+			// the look-ahead was hashed from.
+			if (!missing && la_i < la_n && !is_clean()) {
 				u32 J = 0;
-				while (la_i + J + 1 < la_n && ((la_mask >> (la_i + J + 1)) & 1) &&
-				       (int64_t)h_seq_i + J + 1 <= last_sub_pos && (u64)h_seq_i + J + 1 + p.k - 1 < e.len) {
-					J++;
-				}
+				u32 room = 0xFFFFFFFFu;
 				if (p.event_budget) {
-					const u32 room = steps < p.event_budget ? p.event_budget - steps : 0;
-					J = J < room ? J : room;
+					room = steps < p.event_budget ? p.event_budget - steps : 0;
+				}
+				while (la_i + J + 1 < la_n && ((la_mask >> (la_i + J + 1)) & 1) && J < room) {
+					// one roll of the cursors (roll(), ntedit.cpp:1216-1247) on copies
+					u32 hs2 = h_seq_i, ts2 = t_seq_i, hn2 = h_node, tn2 = t_node;
+					if (hs2 >= e.len || hn2 >= nsize) {
+						break;
+					}
+					increment(hs2, hn2);
+					if (ts2 >= e.len || tn2 >= nsize) {
+						break;
+					}
+					increment(ts2, tn2);
+					if (ts2 >= e.len || tn2 >= nsize || (u64)hs2 + p.k - 1 >= e.len) {
+						break;
+					}
+					const u32 hs1 = h_seq_i, ts1 = t_seq_i, hn1 = h_node, tn1 = t_node;
+					h_seq_i = hs2;
+					t_seq_i = ts2;
+					h_node = hn2;
+					t_node = tn2;
+					if (is_clean()) {
+						h_seq_i = hs1;
+						t_seq_i = ts1;
+						h_node = hn1;
+						t_node = tn1;
+						break;
+					}
+					J++;
 				}
 				if (J) {
 					for (u32 q = 0; q < J; q++) {
 						hash_roll(hs, e.tab, win_o(la_i + q), win_i(la_i + q));
 					}
-					h_seq_i += J;
-					t_seq_i += J;
 					la_i += J;
 					steps += J;
-					char_in = seq_at(t_seq_i);
+					char_in = get_character(t_seq_i, nget(t_node));
 				}
 			}
 			// advance; skip over k-mers containing a non-accepted base (ntedit.cpp:2119-2138)

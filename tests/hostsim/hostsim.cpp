@@ -252,6 +252,9 @@ hostsim_polish(
 			}
 			rerun.clear();
 			rounds++;
+			if (overflow) {
+				break; // a re-run ran out of arena / rope window: the whole batch again with more room (as the C ABI does)
+			}
 			if (!rs.resume(rerun)) {
 				return -7;
 			}

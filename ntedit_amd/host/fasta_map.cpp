@@ -8,6 +8,7 @@
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
+#include <zlib.h>
 
 namespace nte_host {
 
@@ -44,8 +45,9 @@ parallel_for(unsigned threads, size_t n, F f)
 
 } // namespace
 
-FastaMap::FastaMap(const char* path, unsigned threads)
+FastaMap::FastaMap(const char* path, unsigned threads, unsigned inflate_threads)
   : threads_(threads ? threads : 1)
+  , inflate_threads_(inflate_threads ? inflate_threads : threads_)
 {
 	fd_ = open(path, O_RDONLY);
 	if (fd_ < 0) {
@@ -62,6 +64,9 @@ FastaMap::FastaMap(const char* path, unsigned threads)
 	}
 	data_ = (const char*)p;
 	(void)madvise(p, size_, MADV_WILLNEED);
+	if (size_ >= 28 && (unsigned char)data_[0] == 0x1f && (unsigned char)data_[1] == 0x8b && !inflate_bgzf()) {
+		return; // ordinary gzip, or a damaged file: the streaming reader reads (and reports) those
+	}
 	if (data_[0] != '>') {
 		return; // gzip (1f 8b), FASTQ, leading text: the streaming reader's business
 	}
@@ -127,6 +132,101 @@ FastaMap::FastaMap(const char* path, unsigned threads)
 		recs_.pop_back(); // a lone '>' at the very end of the file: kseq finds no name to read and stops
 	}
 	ok_ = true;
+}
+
+// BGZF (the SAM specification, section 4.1): a series of gzip members, each with FLG = FEXTRA and an extra subfield
+// 'B','C' of two bytes holding the member's total size - 1; CRC32 and ISIZE close each member, an empty member ends
+// the file.  Anything that does not fit this exactly makes the function return false with data_/size_ untouched.
+bool
+FastaMap::inflate_bgzf()
+{
+	struct Block
+	{
+		uint64_t in, out; // offsets of the deflate data / of the inflated bytes
+		uint32_t n_in, n_out, crc;
+	};
+	const unsigned char* d = (const unsigned char*)data_;
+	std::vector<Block> blocks;
+	uint64_t o = 0, total = 0;
+	auto u16 = [&](uint64_t at) { return (uint32_t)d[at] | (uint32_t)d[at + 1] << 8; };
+	auto u32 = [&](uint64_t at) { return u16(at) | u16(at + 2) << 16; };
+	while (o < size_) {
+		if (size_ - o < 12 + 6 + 8 || d[o] != 0x1f || d[o + 1] != 0x8b || d[o + 2] != 8 || d[o + 3] != 4) {
+			return false;
+		}
+		const uint32_t xlen = u16(o + 10);
+		if (12 + (uint64_t)xlen + 8 > size_ - o) {
+			return false;
+		}
+		uint32_t bsize = 0;
+		bool have = false;
+		for (uint64_t x = o + 12; x + 4 <= o + 12 + xlen;) {
+			const uint32_t slen = u16(x + 2);
+			if (d[x] == 'B' && d[x + 1] == 'C' && slen == 2 && x + 6 <= o + 12 + xlen) {
+				bsize = u16(x + 4);
+				have = true;
+			}
+			x += 4 + (uint64_t)slen;
+		}
+		const uint64_t member = (uint64_t)bsize + 1;
+		if (!have || member < 12 + (uint64_t)xlen + 8 || member > size_ - o) {
+			return false;
+		}
+		Block b;
+		b.in = o + 12 + xlen;
+		b.n_in = (uint32_t)(member - 12 - xlen - 8);
+		b.crc = u32(o + member - 8);
+		b.n_out = u32(o + member - 4);
+		b.out = total;
+		if (b.n_out > 65536) {
+			return false;
+		}
+		total += b.n_out;
+		blocks.push_back(b);
+		o += member;
+	}
+	if (total < 2) {
+		return false;
+	}
+	void* buf = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	if (buf == MAP_FAILED) {
+		return false;
+	}
+	(void)madvise(buf, total, MADV_HUGEPAGE);
+	std::atomic<bool> good(true);
+	const size_t GROUP = 64; // blocks per task
+	parallel_for(inflate_threads_, (blocks.size() + GROUP - 1) / GROUP, [&](size_t g) {
+		z_stream zs;
+		memset(&zs, 0, sizeof zs);
+		if (inflateInit2(&zs, -15) != Z_OK) {
+			good = false;
+			return;
+		}
+		const size_t hi = (g + 1) * GROUP < blocks.size() ? (g + 1) * GROUP : blocks.size();
+		for (size_t i = g * GROUP; i < hi && good.load(std::memory_order_relaxed); i++) {
+			const Block& b = blocks[i];
+			Bytef* dst = (Bytef*)buf + b.out;
+			zs.next_in = const_cast<Bytef*>(d + b.in);
+			zs.avail_in = b.n_in;
+			zs.next_out = dst;
+			zs.avail_out = b.n_out;
+			const int rc = inflate(&zs, Z_FINISH);
+			if (rc != Z_STREAM_END || zs.avail_out != 0 || zs.avail_in != 0 ||
+			    (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.n_out) != b.crc) {
+				good = false;
+			}
+			inflateReset(&zs);
+		}
+		inflateEnd(&zs);
+	});
+	if (!good) {
+		munmap(buf, total);
+		return false;
+	}
+	munmap((void*)data_, size_);
+	data_ = (const char*)buf;
+	size_ = total;
+	return true;
 }
 
 FastaMap::~FastaMap()

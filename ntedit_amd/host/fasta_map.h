@@ -1,11 +1,13 @@
-// fasta_map.h -- whole-file, multi-threaded FASTA ingest for plain (uncompressed) multi-FASTA files.
+// fasta_map.h -- whole-file, multi-threaded FASTA ingest for plain multi-FASTA files, uncompressed or BGZF
+// (bgzip: gzip members of <= 64 KiB that carry their own compressed size, so they can be found without inflating
+// and inflated independently -- on all threads, where one zlib stream manages 0.35 Gbases/s).
 //
 // The streaming reader (fasta.h) parses with one thread: memchr + one copy per line, ~0.18 s per Gbase, and is
 // the critical path of the `ntedit` binary end to end once the GPU does a Gbase in 60 ms.  A plain FASTA file can be
 // taken apart in parallel: the file is mapped, T threads find the record starts ('>' at the start of a line) in T
 // regions of it, and then measure / copy whole records concurrently straight into the batch buffer.
 // Record semantics are the reference's (kseq, lib/kseq.h:176-215 as used at ntedit.cpp:2223-2230); files that use
-// anything the simple rules below do not cover -- gzip, FASTQ ('@' / '+' at a line start), CR line ends, NUL bytes,
+// anything the simple rules below do not cover -- ordinary (single-stream) gzip, FASTQ ('@' / '+' at a line start), CR line ends, NUL bytes,
 // text in front of the first '>' -- are refused (ok() == false) and go through the streaming reader, which restates
 // kseq character by character.
 #pragma once
@@ -18,7 +20,7 @@ namespace nte_host {
 class FastaMap
 {
   public:
-	FastaMap(const char* path, unsigned threads);
+	FastaMap(const char* path, unsigned threads, unsigned inflate_threads = 0);
 	~FastaMap();
 	FastaMap(const FastaMap&) = delete;
 	FastaMap& operator=(const FastaMap&) = delete;
@@ -40,11 +42,13 @@ class FastaMap
 		uint64_t end;     // offset of the next record's '>' (or the file size)
 		uint64_t len;     // sequence bytes (~0 = not measured yet)
 	};
+	bool inflate_bgzf(); // data_/size_ (the mapped file) -> an anonymous mapping holding the inflated text
 	const char* data_ = nullptr;
 	uint64_t size_ = 0;
 	int fd_ = -1;
 	bool ok_ = false;
 	unsigned threads_ = 1;
+	unsigned inflate_threads_ = 1;
 	std::vector<Rec> recs_;
 };
 

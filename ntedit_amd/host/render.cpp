@@ -15,6 +15,8 @@
 #include <thread>
 #include <string>
 #include <cerrno>
+#include <chrono>
+#include <cstdlib>
 #include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -979,18 +981,26 @@ render_batch(
 		pool.emplace_back(worker);
 	}
 	int rc = 0;
+	const bool timing = getenv("NTEDIT_HIP_DEBUG") != nullptr;
+	double s_wait = 0, s_emit = 0;
 	for (uint32_t u = 0; u < n_units; u++) {
 		ContigOut& o = slots[u % W];
+		const auto tw0 = std::chrono::steady_clock::now();
 		{
 			std::unique_lock<std::mutex> lk(mu);
 			cv_ready.wait(lk, [&]() { return o.ready; });
 		}
+		const auto tw1 = std::chrono::steady_clock::now();
 		if (o.rc) {
 			rc = o.rc;
 			break;
 		}
 		if ((rc = emit_contig(o, fa, tsv, vcf, st, v.opt, unit_begin[u]))) {
 			break;
+		}
+		if (timing) {
+			s_wait += std::chrono::duration<double>(tw1 - tw0).count();
+			s_emit += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw1).count();
 		}
 		{
 			std::lock_guard<std::mutex> lk(mu);
@@ -1006,6 +1016,9 @@ render_batch(
 	cv_free.notify_all();
 	for (std::thread& t : pool) {
 		t.join();
+	}
+	if (timing) {
+		fprintf(stderr, "[ntedit_hip] render: %u units on %u threads, writer waited %.3f s for units, wrote for %.3f s\n", n_units, T, s_wait, s_emit);
 	}
 	return rc;
 }

@@ -261,3 +261,64 @@ def test_mapped_reader_fuzz(tmp_path):
             n_acc += 1
             assert got == model(data), data
     assert n_acc > 100
+
+
+def bgzf_bytes(data, block=65280, rng=None, eof=True):
+    """the BGZF container (SAM specification 4.1) around `data`, written here member by member; with `rng`, block
+    sizes vary (1 byte .. 65280) and empty members are sprinkled in"""
+    import struct
+    import zlib
+    out = []
+
+    def member(chunk):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        assert bsize < 65536
+        out.append(b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize) +
+                   body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+    i = 0
+    while i < len(data):
+        n = block if rng is None else int(rng.integers(1, block + 1))
+        member(data[i:i + n])
+        i += n
+        if rng is not None and rng.integers(0, 9) == 0:
+            member(b"")
+    if eof:
+        member(b"")
+    return b"".join(out)
+
+
+def test_mapped_reader_bgzf(tmp_path):
+    """bgzip-compressed drafts are inflated member by member on all threads and then read like a plain file; an
+    ordinary gzip stream, a damaged member, a truncated file or FASTQ inside go to the streaming reader"""
+    rng = np.random.default_rng(77)
+    parts = []
+    for i in range(40):
+        n = int(rng.integers(0, 200000))
+        s = bytes(rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), n))
+        w = int(rng.integers(1, 120))
+        parts.append((b">s%d some text\n" % i) + b"\n".join(s[j:j + w] for j in range(0, n, w)) + b"\n")
+    data = b"".join(parts)
+    want = model(data)
+    p = str(tmp_path / "in.fa.gz")
+    for variant in range(3):
+        blob = bgzf_bytes(data, rng=rng if variant else None, eof=variant != 2)
+        assert gzip.decompress(blob) == data  # (a valid multi-member gzip file)
+        with open(p, "wb") as f:
+            f.write(blob)
+        assert dump(p, tmp_path) == want  # the streaming reader (zlib's gzread) sees the same text
+        for threads in (1, 5, 16):
+            assert map_dump(p, tmp_path, threads) == want, (variant, threads)
+    blob = bgzf_bytes(data)
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 0x55  # a flipped bit inside some member's deflate data (or header)
+    for broken in (bytes(bad), blob[:len(blob) // 2], blob + b"\x1f\x8b", gzip.compress(data, 1) + bgzf_bytes(b">x\nA\n")):
+        with open(p, "wb") as f:
+            f.write(broken)
+        assert map_dump(p, tmp_path, 4) is None
+    with open(p, "wb") as f:
+        f.write(bgzf_bytes(b"@r1\nACGT\n+\nIIII\n"))
+    assert map_dump(p, tmp_path, 4) is None
+    assert dump(p, tmp_path) == [(b"r1", b"ACGT")]

@@ -548,3 +548,16 @@ def test_cli_mapped_reader_equals_streaming(tmp_path, oracle_build):
         for suf in ("_changes.tsv", "_edited.fa"):
             assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / (tag + suf)), shallow=False), (tag, suf)
         assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / (tag + "_variants.vcf"))), tag
+    # the same draft bgzip-compressed (inflated member by member on all threads), and as one ordinary gzip stream
+    from test_fasta_reader import bgzf_bytes
+    import gzip
+    data = open(case["draft"], "rb").read()
+    for tag, blob in (("bg", bgzf_bytes(data)), ("gz", gzip.compress(data, 1))):
+        path = str(tmp_path / (tag + ".fa.gz"))
+        with open(path, "wb") as f:
+            f.write(blob)
+        r = subprocess.run([cli, "-f", path, "-r", case["bf"], "-b", str(tmp_path / tag), "-z", "200", "--batch-bases", "150000"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for suf in ("_changes.tsv", "_edited.fa"):
+            assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / (tag + suf)), shallow=False), (tag, suf)

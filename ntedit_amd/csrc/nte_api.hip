@@ -358,7 +358,10 @@ launch_screen(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d
 bool
 binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_log2, u32* n_slices)
 {
-	const u32 mode = c->hp.screen_mode;
+	u32 mode = c->hp.screen_mode;
+	if (const char* e = getenv("NTEDIT_HIP_SCREEN_MODE")) { // test hook (the fuzz forces the pipeline on small cases)
+		mode = (u32)atoi(e);
+	}
 	if (mode == 1 || f.hash_num == 0 || f.hash_num > 5 || f.counting || c->hp.snv) {
 		return false;
 	}

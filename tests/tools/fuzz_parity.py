@@ -112,9 +112,19 @@ def main():
                     cmd += ["--batch-bases", str(int(rng.choice([1, 5000, 30000, 100000])))]
                 if rng.random() < 0.5:
                     cmd += ["-t", str(int(rng.integers(1, 9)))]
-                if rng.random() < 0.25:
+                zdraw = rng.random()
+                if zdraw < 0.25:
                     subprocess.run(["gzip", "-k", "-1", case["draft"]], check=True)
                     cmd[cmd.index("-f") + 1] = case["draft"] + ".gz"
+                elif zdraw < 0.4:
+                    from test_fasta_reader import bgzf_bytes  # (bgzip container: inflated member by member, in parallel)
+                    with open(case["draft"], "rb") as f, open(case["draft"] + ".bgz", "wb") as o:
+                        o.write(bgzf_bytes(f.read(), block=int(rng.choice([100, 4000, 65280]))))
+                    cmd[cmd.index("-f") + 1] = case["draft"] + ".bgz"
+                # the L2-partitioned screening pipeline on small inputs, in several record chunks
+                if rng.random() < 0.35:
+                    env["NTEDIT_HIP_SCREEN_MODE"] = "2"
+                    env["NTEDIT_HIP_BIN_CHUNK"] = str(int(rng.choice([16384, 3 * 16384, 1 << 20])))
                 if "start_grid" in par_kw:
                     cmd += ["--start-grid", str(par_kw["start_grid"])]
                 if "event_budget" in par_kw:

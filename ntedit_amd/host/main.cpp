@@ -384,13 +384,7 @@ main(int argc, char** argv)
 	// polish_batch calls of a 3 Gbp draft, and end to end the renderer is the critical path anyway.  Batches are
 	// ordinary memory; the runtime stages their pieces.)
 	Work pool[3];
-	std::thread pin_helper; // (kept: nothing to join)
-	auto fatal = [&]() {
-		if (pin_helper.joinable()) {
-			pin_helper.join(); // (never leave the process while the helper is inside the HIP runtime)
-		}
-		exit(EXIT_FAILURE);
-	};
+	auto fatal = [&]() { exit(EXIT_FAILURE); };
 	time(&rawtime);
 	printf("---------- loading Bloom filter from file           : %s\n", ctime(&rawtime));
 	if (ntedit_hip_load_filter_file(ctx, NTEDIT_FILTER_PRIMARY, bf.c_str()) != 0) {
@@ -576,9 +570,6 @@ main(int argc, char** argv)
 	// into batch N+1 while the GPU polishes batch N and the writer renders batch N-1.
 	// Output order = input order (the reference at -t 1).
 	Channel free_q, gpu_q, write_q;
-	if (pin_helper.joinable()) {
-		pin_helper.join();
-	}
 	for (Work& w : pool) {
 		free_q.push(&w);
 	}

@@ -250,6 +250,9 @@ refresh_params(ntedit_hip_ctx* c)
 	if (const char* e = getenv("NTEDIT_HIP_MACHINE_DEBUG")) {
 		c->dp.debug_stop = (u32)atoi(e); // timing ablations; results are NOT valid
 	}
+	if (const char* e = getenv("NTEDIT_HIP_INLINE_TRIES")) { // tuning / tests (any value gives the same results)
+		c->dp.inline_tries = (u32)atoi(e);
+	}
 	if (!c->d_tab) {
 		HIP_TRY(c, hipMalloc((void**)&c->d_tab, TAB_WORDS * sizeof(u64)));
 	}

@@ -318,6 +318,7 @@ struct DevParams
 	u32 start_grid;    // extra event start every start_grid positions inside an absent run
 	u32 node_window;   // live rope nodes kept per event thread
 	u32 event_budget;  // positions an event may walk before it is parked as EV_UNFINISHED (0 = no limit)
+	u32 inline_tries;  // a launch that postpones indel sweeps still tries this many candidates of one itself (see nte_machine.h)
 	u32 debug_stop;    // timing ablations only (NTEDIT_HIP_MACHINE_DEBUG): 1 seed, 2 step 2, 4 first position
 	u32 counting;      // primary filter is a counting filter
 	u32 snv;           // -s 1: every position is re-assessed (ntedit.cpp:1806,1865)

@@ -1330,8 +1330,10 @@ struct Machine
 	// lengths still untried at this failing position).  try number t of that list goes to
 	// lane t % wave_size; the first accepted try in list order is the result, so evaluating
 	// later tries speculatively cannot change it.  Needs the character window (win_ok).
-	NTE_HD bool
-	try_indels_first_accepted(u8 draft_char, u8 index_char, u32& num_deletions, Best& b)
+	// limit: stop after the first `limit` tries of the list (0 = all of them); returns 1 accepted, 0 nothing accepted
+	// among all tries, -1 undecided (none of the first `limit`, more to try: nothing has been changed)
+	NTE_HD int
+	try_indels_first_accepted(u8 draft_char, u8 index_char, u32& num_deletions, Best& b, u32 limit = 0)
 	{
 		const u32 W = e.wave_size;
 		const u32 lane = wave_lane();
@@ -1342,12 +1344,13 @@ struct Machine
 			D = p.ins_tries;
 		}
 		const u32 total = p.ins_tries + D;
-		for (u32 base = 0; base < total; base += W) {
+		const u32 stop = limit && limit < total ? limit : total;
+		for (u32 base = 0; base < stop; base += W) {
 			const u32 t = base + lane;
 			u32 support = 0;
 			bool is_del = false;
 			u32 idx = 0; // insertion index or deletion length
-			if (t < total) {
+			if (t < stop) {
 				if (t < 2 * D) {
 					is_del = (t & 1) != 0;
 					idx = is_del ? nd0 + (t >> 1) : (t >> 1);
@@ -1383,11 +1386,14 @@ struct Machine
 					b.n_indel = insertion_candidate(index_char, ii, b.indel);
 				}
 				b.num_support = sup;
-				return true;
+				return 1;
 			}
 		}
+		if (stop < total) {
+			return -1;
+		}
 		num_deletions = nd0 + D;
-		return false;
+		return 0;
 	}
 
 	// ntedit.cpp:1548-1744
@@ -1396,7 +1402,7 @@ struct Machine
 	{
 		NTE_COUNT(sweeps, 1);
 		if (p.mode == 0 && win_ok) {
-			return try_indels_first_accepted(draft_char, index_char, num_deletions, b);
+			return try_indels_first_accepted(draft_char, index_char, num_deletions, b) > 0;
 		}
 		u32 temp_best_support = 0, temp_alt_support = 0;
 		u8 temp_best_indel[12];
@@ -2018,14 +2024,28 @@ struct Machine
 				if (p.debug_stop == 3) {
 					return; // timing ablation: everything up to the first indel sweep
 				}
+				bool accepted;
 				if (e.defer_sweeps && p.ins_tries > 0) {
 					// the candidate sweep is ~100x the cost of everything else an event
 					// does; running it next to 63 cheap lanes would idle the wave, so the
-					// first pass hands such events to a second, sweep-only launch
-					flags |= EV_DEFERRED;
-					return;
+					// first pass hands such events to a second, sweep-only launch.  But a quarter of
+					// those events only ever meet sweeps whose first few tries succeed (a one-base
+					// indel: the index base alone, or a deletion of one): the first inline_tries
+					// candidates are tried here, in list order -- the first accepted one is the sweep's
+					// result whatever comes behind it.
+					int r = -1;
+					if (p.mode == 0 && win_ok && p.inline_tries) {
+						r = try_indels_first_accepted(draft_char, sub_base, num_deletions, b, p.inline_tries);
+					}
+					if (r < 0) {
+						flags |= EV_DEFERRED;
+						return;
+					}
+					accepted = r > 0;
+				} else {
+					accepted = try_indels(draft_char, sub_base, num_deletions, b);
 				}
-				if (try_indels(draft_char, sub_base, num_deletions, b)) {
+				if (accepted) {
 					if (p.mode == 0 || p.mode == 1) {
 						break;
 					}

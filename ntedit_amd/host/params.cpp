@@ -147,6 +147,7 @@ make_dev_params(
 		budget = 2 * g;
 	}
 	d.event_budget = budget;
+	d.inline_tries = 4;
 	for (uint32_t i = 0; i < nte::MAX_HASHES; i++) {
 		d.mul[i] = (uint64_t)i ^ ((uint64_t)k * nte::MULTISEED);
 	}

@@ -181,6 +181,9 @@ hostsim_polish(
 		const u32 ci = ev_contig[idx];
 		DevParams pe = p;
 		pe.event_budget = budget;
+		if (const char* it = getenv("HOSTSIM_INLINE_TRIES")) {
+			pe.inline_tries = (u32)atoi(it);
+		}
 		EventEnv env;
 		env.seq = (const u8*)bases + offsets[ci];
 		env.batch_end = (const u8*)bases + n;

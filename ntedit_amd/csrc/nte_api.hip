@@ -1627,12 +1627,14 @@ PolishRun::run_chunk_events(size_t j)
 		    "machine %.3f ms (sweep launches %.3f ms) arena %u status %u window %u\n",
 		    j + 1, n_ch, ch.c0, ch.c1, (unsigned long long)n_ev, n_A, n_B, n_C,
 		    (unsigned long long)(rounds ? (u64)n32 - n_A - n_B - n_C : 0), n_def, p_all, p2_ms, h_tail[0], status, c->dp.node_window);
-		unsigned long long pr[16];
+		unsigned long long pr[24];
 		machine_wave_profile(pr);
 		if (pr[8]) {
 			fprintf(stderr, "[ntedit_hip] wave-kernel phase cycles/event (n=%llu): seed %llu presence %llu first-miss %llu later-miss %llu advance %llu loop %llu housekeeping %llu flush %llu; positions/event %.1f failing %.1f\n",
 			    pr[8], pr[0] / pr[8], pr[1] / pr[8], pr[2] / pr[8], pr[3] / pr[8], pr[4] / pr[8], pr[5] / pr[8], pr[6] / pr[8], pr[7] / pr[8],
 			    (double)pr[9] / (double)pr[8], (double)pr[10] / (double)pr[8]);
+			fprintf(stderr, "[ntedit_hip]   inside failing positions: window %llu step-2 %llu substitutions %llu indel sweeps %llu apply %llu\n",
+			    pr[16] / pr[8], pr[17] / pr[8], pr[18] / pr[8], pr[20] / pr[8], pr[19] / pr[8]);
 		}
 	}
 	ev_total += n_ev;

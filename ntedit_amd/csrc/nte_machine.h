@@ -41,7 +41,7 @@ extern WorkCounters g_wc;
 // Phase timers of the wavefront-per-event kernel (build nte_machine_wave.hip with
 // -DNTE_PROFILE): shader cycles per phase, summed over events into g_prof[].
 #if defined(NTE_PROFILE)
-__device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_prof[24];
 #endif
 #if defined(NTE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define NTE_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, prof_cnt[4] = { 0, 0, 0, 0 }
@@ -52,11 +52,18 @@ __device__ unsigned long long g_prof[16];
 		prof_acc[slot] += now_ - prof_t;                                  \
 		prof_t = now_;                                                    \
 	} while (0)
+#define NTE_PROF_SUB(slot)                                                \
+	do {                                                                  \
+		const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+		prof_sub[slot] += now_ - prof_sub_t;                              \
+		prof_sub_t = now_;                                                \
+	} while (0)
 #define NTE_PROF_FLUSH                                                    \
 	do {                                                                  \
 		if ((threadIdx.x & (e.wave_size - 1u)) == 0) {                    \
 			for (int i_ = 0; i_ < 8; i_++) {                              \
 				atomicAdd(&g_prof[i_], prof_acc[i_]);                     \
+				atomicAdd(&g_prof[16 + i_], prof_sub[i_]);                \
 			}                                                             \
 			atomicAdd(&g_prof[8], 1ull);                                  \
 			for (int i_ = 0; i_ < 4; i_++) {                              \
@@ -68,6 +75,7 @@ __device__ unsigned long long g_prof[16];
 #define NTE_PROF_DECL ((void)0)
 #define NTE_PROF_COUNT(slot) ((void)0)
 #define NTE_PROF(slot) ((void)0)
+#define NTE_PROF_SUB(slot) ((void)0)
 #define NTE_PROF_FLUSH ((void)0)
 #endif
 
@@ -166,6 +174,9 @@ struct Machine
 	// presence of the next k-mers while the window still overlaps an edit (see build_lookahead)
 	u32 la_mask, la_n, la_i;
 	bool la_off;
+#if defined(NTE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+	unsigned long long prof_sub_t = 0, prof_sub[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
 
 	NTE_HD
 	Machine(const EventEnv& env)
@@ -1787,7 +1798,9 @@ struct Machine
 		// step 2: confirm on the k/j subset (ntedit.cpp:1826-1858)
 		u32 check_missing = 0;
 		bool do_not_fix = false;
+		NTE_PROF_SUB(7); // (time outside process_missing)
 		win_ok = fill_window();
+		NTE_PROF_SUB(0);
 		u32 check_there = 0, there_median = 0;
 		if (e.bloom.counting || p.snv) {
 			// counting filter / SNV mode (ntedit.cpp:1842-1861,1873,1890-1914): besides the
@@ -1893,6 +1906,7 @@ struct Machine
 			return;
 		}
 
+		NTE_PROF_SUB(1); // step 2
 		u32 num_deletions = 1;
 		Best b;
 		b.edit_type = 0;
@@ -2028,7 +2042,7 @@ struct Machine
 				if (e.defer_sweeps && p.ins_tries > 0) {
 					// the candidate sweep is ~100x the cost of everything else an event
 					// does; running it next to 63 cheap lanes would idle the wave, so the
-					// first pass hands such events to a second, sweep-only launch.  But a quarter of
+					// first pass hands such events to a second, sweep-only launch.  But two thirds of
 					// those events only ever meet sweeps whose first few tries succeed (a one-base
 					// indel: the index base alone, or a deletion of one): the first inline_tries
 					// candidates are tried here, in list order -- the first accepted one is the sweep's
@@ -2043,7 +2057,9 @@ struct Machine
 					}
 					accepted = r > 0;
 				} else {
+					NTE_PROF_SUB(2);
 					accepted = try_indels(draft_char, sub_base, num_deletions, b);
+					NTE_PROF_SUB(4); // indel sweep
 				}
 				if (accepted) {
 					if (p.mode == 0 || p.mode == 1) {
@@ -2052,7 +2068,9 @@ struct Machine
 				}
 			}
 		}
+		NTE_PROF_SUB(2); // candidates (substitutions + indel sweeps)
 		make_edit(draft_char, b);
+		NTE_PROF_SUB(3);
 	}
 
 	// run one event that starts (clean) with its k-mer head at local position start

@@ -65,6 +65,6 @@ void launch_k_machine_thread(unsigned blocks, size_t dyn_lds, hipStream_t stream
 void launch_k_machine_wave(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);
 // lanes per event in that kernel (a 256-thread block runs 256 / group events at a time)
 int machine_wave_group();
-void machine_wave_profile(unsigned long long out[16]);
+void machine_wave_profile(unsigned long long out[24]);
 
 } // namespace nte

@@ -11,13 +11,13 @@ launch_k_machine_wave(unsigned blocks, size_t dyn_lds, hipStream_t stream, const
 
 // phase timers (all zero unless built with -DNTE_PROFILE); reading resets them
 void
-machine_wave_profile(unsigned long long out[16])
+machine_wave_profile(unsigned long long out[24])
 {
-	for (int i = 0; i < 16; i++) {
+	for (int i = 0; i < 24; i++) {
 		out[i] = 0;
 	}
 #if defined(NTE_PROFILE)
-	unsigned long long zero[16] = { 0 };
+	unsigned long long zero[24] = { 0 };
 	(void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof zero);
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof zero);
 #endif

@@ -147,7 +147,7 @@ make_dev_params(
 		budget = 2 * g;
 	}
 	d.event_budget = budget;
-	d.inline_tries = 4;
+	d.inline_tries = 8; // (3 Gbp bench, sweep launch at 64 lanes per event: 4 / 8 / 16 tries -> machine 47.8 / 47.2 / 47.6 ms)
 	for (uint32_t i = 0; i < nte::MAX_HASHES; i++) {
 		d.mul[i] = (uint64_t)i ^ ((uint64_t)k * nte::MULTISEED);
 	}

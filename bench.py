@@ -185,7 +185,10 @@ def measured_regions(job, pol, args):
                 f.write(hnp[o:o + l + 1].tobytes())  # sequence + '\n'
         runs = []
         os.sync()  # (dirty pages of whatever ran before -- this draft, test outputs -- are written back first)
-        for _ in range(3):
+        # The CLI runs as a child of this process, which keeps its own context on the same GPU: about every other run
+        # its host-to-device copies crawl (polish calls 0.9 s instead of 0.37 s; by hand, without this parent, never --
+        # tools/gpu_numa.sh).  Hence the best of five.
+        for _ in range(5):
             for suf in ("_edited.fa", "_changes.tsv", "_variants.vcf"):  # (every run starts without output files)
                 if os.path.exists(os.path.join(work, "out" + suf)):
                     os.unlink(os.path.join(work, "out" + suf))
@@ -212,7 +215,7 @@ def measured_regions(job, pol, args):
             "output_bytes": os.path.getsize(os.path.join(work, "out_edited.fa")),
             "note": "`ntedit -f draft.fa -r truth.bf` on local disk, region = the reference's 'reading/processing "
                     "input sequence' -> 'process complete' stamps; the three stages overlap (pipeline); process wall "
-                    "adds reading the 4 GiB filter file into HBM; best of 3 runs"}
+                    "adds reading the 4 GiB filter file into HBM; best of 5 runs"}
         if args.e2e_bgzf:
             gz = os.path.join(work, "draft.fa.gz")
             t0 = time.perf_counter()
@@ -233,7 +236,10 @@ def measured_regions(job, pol, args):
     except Exception as e:  # pragma: no cover
         out["end_to_end"] = {"error": str(e)}
     finally:
-        shutil.rmtree(work, ignore_errors=True)
+        if os.environ.get("NTEDIT_BENCH_KEEP_E2E"):  # experiments: keep draft.fa / truth.bf for runs by hand
+            sys.stderr.write("[bench] end-to-end inputs kept in %s\n" % work)
+        else:
+            shutil.rmtree(work, ignore_errors=True)
     del host
     return out
 

@@ -105,7 +105,7 @@ EXPORTS = [
     "ntedit_hip_annot_load", "ntedit_hip_annot_free", "ntedit_hip_write_vcf_header", "ntedit_hip_write_outputs_vcf",
     "ntedit_hip_set_host_threads", "ntedit_hip_filter_occupancy",
     "ntedit_hip_write_outputs_ex", "ntedit_hip_result_cover_ends", "ntedit_hip_result_edits",
-    "ntedit_hip_host_alloc", "ntedit_hip_host_free",
+    "ntedit_hip_host_alloc", "ntedit_hip_host_free", "ntedit_hip_bind_near_device",
 ]
 
 _lib = None
@@ -166,6 +166,7 @@ def load():
     lib.ntedit_hip_host_alloc.restype = vp
     lib.ntedit_hip_host_free.argtypes = [vp]
     lib.ntedit_hip_host_free.restype = None
+    lib.ntedit_hip_bind_near_device.argtypes = [ci]
     lib.ntedit_hip_filter_occupancy.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.ntedit_hip_set_host_threads.argtypes = [ctypes.c_uint]
     lib.ntedit_hip_set_host_threads.restype = None

@@ -12,11 +12,13 @@
 #include "../host/resolve.h"
 
 #include <atomic>
+#include <cctype>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <sched.h>
 #include <string>
 #include <vector>
 
@@ -2138,6 +2140,79 @@ ntedit_hip_host_free(void* p)
 	if (p) {
 		(void)hipHostFree(p);
 	}
+}
+
+int
+ntedit_hip_bind_near_device(int device)
+{
+	if (getenv("NTEDIT_HIP_NO_BIND")) {
+		return -1;
+	}
+	char id[64] = { 0 };
+	if (hipDeviceGetPCIBusId(id, (int)sizeof id - 1, device) != hipSuccess) {
+		return -1;
+	}
+	for (char* q = id; *q; q++) {
+		*q = (char)tolower((unsigned char)*q);
+	}
+	char path[256];
+	snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", id);
+	FILE* f = fopen(path, "r");
+	if (!f) {
+		return -1;
+	}
+	int node = -1;
+	if (fscanf(f, "%d", &node) != 1) {
+		node = -1;
+	}
+	fclose(f);
+	if (node < 0) {
+		return -1;
+	}
+	snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+	f = fopen(path, "r");
+	if (!f) {
+		return -1;
+	}
+	// "0-63,128-191"
+	cpu_set_t want;
+	CPU_ZERO(&want);
+	int lo = 0, hi = 0, n_set = 0;
+	for (;;) {
+		if (fscanf(f, "%d", &lo) != 1) {
+			break;
+		}
+		hi = lo;
+		int ch = fgetc(f);
+		if (ch == '-') {
+			if (fscanf(f, "%d", &hi) != 1) {
+				break;
+			}
+			ch = fgetc(f);
+		}
+		for (int cpu = lo; cpu <= hi && cpu < CPU_SETSIZE; cpu++) {
+			CPU_SET(cpu, &want);
+			n_set++;
+		}
+		if (ch != ',') {
+			break;
+		}
+	}
+	fclose(f);
+	// only CPUs the process may use anyway; nothing to do when that leaves none (or all)
+	cpu_set_t have;
+	if (n_set == 0 || sched_getaffinity(0, sizeof have, &have) != 0) {
+		return -1;
+	}
+	cpu_set_t both;
+	CPU_AND(&both, &want, &have);
+	if (CPU_COUNT(&both) == 0 || CPU_COUNT(&both) == CPU_COUNT(&have)) {
+		return -1;
+	}
+	if (sched_setaffinity(0, sizeof both, &both) != 0) {
+		return -1;
+	}
+	return node;
 }
 
 void

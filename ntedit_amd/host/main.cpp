@@ -380,6 +380,8 @@ main(int argc, char** argv)
 		fprintf(stderr, PROGRAM ": error: no usable HIP device %d (this build has no CPU path).\n", gpu);
 		exit(EXIT_FAILURE);
 	}
+	// every thread and batch buffer from here on: on the socket the GPU hangs off
+	(void)ntedit_hip_bind_near_device(gpu);
 	// (Page-locking the batch buffers was tried: 3 x 1.07 GiB cost 1.3 s of process time for 0.07 s less in the
 	// polish_batch calls of a 3 Gbp draft, and end to end the renderer is the critical path anyway.  Batches are
 	// ordinary memory; the runtime stages their pieces.)

@@ -139,6 +139,7 @@ def main(argv=None):
         os.environ.setdefault("MASTER_PORT", "29513")
         dist.init_process_group(backend=args.backend, rank=0, world_size=1)
     pol = Polisher(local)
+    pol._lib.ntedit_hip_bind_near_device(local)  # host threads and buffers on the socket this rank's GPU hangs off
     t0 = time.perf_counter()
     ndist.load_and_broadcast_filter(pol, args.bf, 0, 0)
     if args.bfrep:

@@ -366,6 +366,7 @@ def main():
     dev = torch.device("cuda", local)
 
     pol = ntedit_amd.Polisher(local)
+    pol._lib.ntedit_hip_bind_near_device(local)  # this rank's host side on the socket its GPU hangs off
     pol.set_params(ntedit_amd.default_params(start_grid=args.start_grid, screen_mode=args.screen_mode))
     t_setup = time.perf_counter()
     # the same truth genome and the same draft on every rank; rank 0 builds the filter and broadcasts it (RCCL)

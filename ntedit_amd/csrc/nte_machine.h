@@ -174,6 +174,8 @@ struct Machine
 	// presence of the next k-mers while the window still overlaps an edit (see build_lookahead)
 	u32 la_mask, la_n, la_i;
 	bool la_off;
+	bool changed_seq; // the last failing position applied an edit (else the sequence, and the look-ahead, still stand)
+	bool la_win;      // the character window is still the one the look-ahead was hashed from (the stride needs it)
 #if defined(NTE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 	unsigned long long prof_sub_t = 0, prof_sub[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
@@ -1759,6 +1761,7 @@ struct Machine
 				la_mask |= (u32)((wave_ballot(present) & 0xFFFFFFFFull) << base);
 			}
 			la_n = L;
+			la_win = true;
 			return;
 		}
 		HashState ts = hs;
@@ -1781,6 +1784,7 @@ struct Machine
 			n += nb;
 		}
 		la_n = L;
+		la_win = true;
 	}
 
 	// steps 2-5 + makeEdit for the k-mer currently under the cursors
@@ -2069,6 +2073,7 @@ struct Machine
 			}
 		}
 		NTE_PROF_SUB(2); // candidates (substitutions + indel sweeps)
+		changed_seq = b.edit_type != 0;
 		make_edit(draft_char, b);
 		NTE_PROF_SUB(3);
 	}
@@ -2095,6 +2100,8 @@ struct Machine
 		win_off = 0;
 		la_mask = la_n = la_i = 0;
 		la_off = false;
+		la_win = false;
+		changed_seq = false;
 		first_chunk = cur_chunk = NONE32;
 		fill = 0;
 		flags = 0;
@@ -2197,10 +2204,15 @@ struct Machine
 			first = false;
 			if (missing) {
 				NTE_PROF_COUNT(1);
+				changed_seq = false;
 				process_missing(char_in);
 				NTE_PROF(was_first ? 2 : 3); // first / later failing positions
-				la_n = la_i = 0; // the sequence may have changed: look ahead afresh
-				la_off = false;
+				la_win = false; // (the failing position filled the window for itself)
+				if (changed_seq) {
+					la_n = la_i = 0; // the sequence has changed: look ahead afresh
+					la_off = false;
+				}
+				// (an error nothing fixes fails at every k-mer that covers it: the k-mers ahead are the same ones)
 			}
 			if (p.debug_stop >= 2 && p.debug_stop < 8) {
 				cover_end = e.len;
@@ -2221,7 +2233,7 @@ struct Machine
 			// looked-ahead, present, inside the contig and still dirty -- where the machine would be clean the
 			// main loop has to consult the screening bitmap itself -- and the hash is rolled from the window codes
 			// the look-ahead was hashed from.
-			if (!missing && la_i < la_n && !is_clean()) {
+			if (!missing && la_i < la_n && la_win && !is_clean()) {
 				u32 J = 0;
 				u32 room = 0xFFFFFFFFu;
 				if (p.event_budget) {

@@ -1635,8 +1635,8 @@ PolishRun::run_chunk_events(size_t j)
 			fprintf(stderr, "[ntedit_hip] wave-kernel phase cycles/event (n=%llu): seed %llu presence %llu first-miss %llu later-miss %llu advance %llu loop %llu housekeeping %llu flush %llu; positions/event %.1f failing %.1f\n",
 			    pr[8], pr[0] / pr[8], pr[1] / pr[8], pr[2] / pr[8], pr[3] / pr[8], pr[4] / pr[8], pr[5] / pr[8], pr[6] / pr[8], pr[7] / pr[8],
 			    (double)pr[9] / (double)pr[8], (double)pr[10] / (double)pr[8]);
-			fprintf(stderr, "[ntedit_hip]   inside failing positions: window %llu step-2 %llu substitutions %llu indel sweeps %llu apply %llu\n",
-			    pr[16] / pr[8], pr[17] / pr[8], pr[18] / pr[8], pr[20] / pr[8], pr[19] / pr[8]);
+			fprintf(stderr, "[ntedit_hip]   inside failing positions: window %llu step-2 %llu substitutions %llu indel sweeps %llu apply %llu; advance: stride %llu roll %llu\n",
+			    pr[16] / pr[8], pr[17] / pr[8], pr[18] / pr[8], pr[20] / pr[8], pr[19] / pr[8], pr[21] / pr[8], pr[22] / pr[8]);
 		}
 	}
 	ev_total += n_ev;

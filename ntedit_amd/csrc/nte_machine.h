@@ -467,6 +467,28 @@ struct Machine
 		}
 	}
 
+	// increment() with the node under the cursor kept by the caller (n == nget(node_index) on entry and on return)
+	NTE_HD void
+	increment_cached(u32& pos, u32& node_index, Node& n) const
+	{
+		if (n.type == 0) {
+			pos++;
+			if (pos > n.e_pos) {
+				node_index++;
+				n = nget(node_index);
+				if (n.type == 0) {
+					pos = n.s_pos;
+				}
+			}
+		} else if (n.type == 1) {
+			node_index++;
+			n = nget(node_index);
+			if (n.type == 0) {
+				pos = n.s_pos;
+			}
+		}
+	}
+
 	// ntedit.cpp:1216-1247
 	NTE_HD bool
 	roll(u32& hs_i, u32& ts_i, u32& hn, u32& tn, u8& char_out, u8& char_in) const
@@ -1704,6 +1726,25 @@ struct Machine
 	// a function of the un-edited draft: both cursors sit in the open-ended last
 	// position node, the window is k contiguous draft bases, no substituted
 	// base is still inside it.
+	// is_clean() for cursors held by the caller (tail = nget(tn))
+	NTE_HD bool
+	clean_at(u32 hs_i, u32 ts_i, u32 hn, u32 tn, const Node& tail) const
+	{
+		if (hn != tn) {
+			return false;
+		}
+		if (tail.type != 0 || tail.e_pos != e.len - 1) {
+			return false;
+		}
+		if (tn + 1 < nsize && nget(tn + 1).type != -1) {
+			return false;
+		}
+		if (ts_i != hs_i + p.k - 1 || hs_i < tail.s_pos) {
+			return false;
+		}
+		return (int64_t)hs_i > last_sub_pos;
+	}
+
 	NTE_HD bool
 	is_clean() const
 	{
@@ -2233,41 +2274,47 @@ struct Machine
 			// looked-ahead, present, inside the contig and still dirty -- where the machine would be clean the
 			// main loop has to consult the screening bitmap itself -- and the hash is rolled from the window codes
 			// the look-ahead was hashed from.
+			NTE_PROF_SUB(7);
 			if (!missing && la_i < la_n && la_win && !is_clean()) {
 				u32 J = 0;
 				u32 room = 0xFFFFFFFFu;
 				if (p.event_budget) {
 					room = steps < p.event_budget ? p.event_budget - steps : 0;
 				}
+				// (the nodes under the two cursors are kept in registers: a roll inside a node costs no rope access)
+				Node nh = nget(h_node), nt = nget(t_node);
+				u32 hs2 = h_seq_i, ts2 = t_seq_i, hn2 = h_node, tn2 = t_node;
 				while (la_i + J + 1 < la_n && ((la_mask >> (la_i + J + 1)) & 1) && J < room) {
 					// one roll of the cursors (roll(), ntedit.cpp:1216-1247) on copies
-					u32 hs2 = h_seq_i, ts2 = t_seq_i, hn2 = h_node, tn2 = t_node;
-					if (hs2 >= e.len || hn2 >= nsize) {
+					u32 hs3 = hs2, ts3 = ts2, hn3 = hn2, tn3 = tn2;
+					Node nh3 = nh, nt3 = nt;
+					if (hs3 >= e.len || hn3 >= nsize) {
 						break;
 					}
-					increment(hs2, hn2);
-					if (ts2 >= e.len || tn2 >= nsize) {
+					increment_cached(hs3, hn3, nh3);
+					if (ts3 >= e.len || tn3 >= nsize) {
 						break;
 					}
-					increment(ts2, tn2);
-					if (ts2 >= e.len || tn2 >= nsize || (u64)hs2 + p.k - 1 >= e.len) {
+					increment_cached(ts3, tn3, nt3);
+					if (ts3 >= e.len || tn3 >= nsize || (u64)hs3 + p.k - 1 >= e.len) {
 						break;
 					}
-					const u32 hs1 = h_seq_i, ts1 = t_seq_i, hn1 = h_node, tn1 = t_node;
+					if (clean_at(hs3, ts3, hn3, tn3, nt3)) {
+						break; // where the machine would be clean the main loop consults the screening bitmap itself
+					}
+					hs2 = hs3;
+					ts2 = ts3;
+					hn2 = hn3;
+					tn2 = tn3;
+					nh = nh3;
+					nt = nt3;
+					J++;
+				}
+				if (J) {
 					h_seq_i = hs2;
 					t_seq_i = ts2;
 					h_node = hn2;
 					t_node = tn2;
-					if (is_clean()) {
-						h_seq_i = hs1;
-						t_seq_i = ts1;
-						h_node = hn1;
-						t_node = tn1;
-						break;
-					}
-					J++;
-				}
-				if (J) {
 					for (u32 q = 0; q < J; q++) {
 						hash_roll(hs, e.tab, win_o(la_i + q), win_i(la_i + q));
 					}
@@ -2276,6 +2323,7 @@ struct Machine
 					char_in = get_character(t_seq_i, nget(t_node));
 				}
 			}
+			NTE_PROF_SUB(5); // stride
 			// advance; skip over k-mers containing a non-accepted base (ntedit.cpp:2119-2138)
 			bool ended = false;
 			int64_t target = -1;
@@ -2296,6 +2344,7 @@ struct Machine
 				cover_end = e.len;
 				break;
 			}
+			NTE_PROF_SUB(6); // roll
 			NTE_PROF(4); // advance
 			housekeeping();
 			NTE_PROF(6);

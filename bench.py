@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-weak", action="store_true", help="skip the weak-scaling leg at N>1")
     ap.add_argument("--e2e-bgzf", action="store_true", help="also run the end-to-end region on a BGZF-compressed draft")
     ap.add_argument("--no-regions", action="store_true", help="skip the host-buffer and end-to-end regions (N=1)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="ntedit_hip_set_tuning knob (repeatable; none of them changes a result)")
     ap.add_argument("--shared-filter", action="store_true",
                     help="use the multi-GPU filter path (torch-owned filter tensor + broadcast) even with 1 rank")
     return ap.parse_args()
@@ -366,6 +368,9 @@ def main():
     dev = torch.device("cuda", local)
 
     pol = ntedit_amd.Polisher(local)
+    for kv in args.tune:
+        key, _, val = kv.partition("=")
+        pol.set_tuning(key, int(val))
     pol._lib.ntedit_hip_bind_near_device(local)  # this rank's host side on the socket its GPU hangs off
     pol.set_params(ntedit_amd.default_params(start_grid=args.start_grid, screen_mode=args.screen_mode))
     t_setup = time.perf_counter()
@@ -409,11 +414,11 @@ def main():
             st = res.stats()
             if check_halos is not None:
                 # (warm-up only) every cut of this rank's segments must verify, as the driver checks it
-                cover = res.cover_ends(len(lens)).astype(np.int64)
+                ok = res.cuts_ok(lens, [(0, int(h), 0) for h in check_halos])
                 # (the driver polishes such a segment again, joined with its successor; with the bench's filter
                 # load none is expected -- a draft whose serial run ends early in a contig, as the reference's does
                 # at false-positive rates of several percent, makes every later cut of that contig one)
-                cuts_rejected[0] = int(((check_halos > 0) & (cover > lens.astype(np.int64) - check_halos)).sum())
+                cuts_rejected[0] = int((~ok).sum())
             res.free()
             launches[0] = max(1, int(st.screen_launches))
             return st, st.ms_screen

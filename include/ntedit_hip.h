@@ -237,7 +237,7 @@ int ntedit_hip_write_outputs_vcf(
  * anywhere else, starts from the same state.  The caller places c inside a run of k-mers that are all in
  * the filter (ntedit_amd/dist.py: refine_cut); the library VERIFIES the cut from the edit records --
  * every applied event ended at or before c and nothing behind c was touched -- and refuses to render
- * the entry otherwise (NTEDIT_E_SEGMENT; ntedit_hip_result_cover_ends() lets the caller check first and
+ * the entry otherwise (NTEDIT_E_SEGMENT; ntedit_hip_result_cuts_ok() lets the caller check first and
  * re-run the segment joined with its successor).  Concatenating the segments' output is then byte-identical to
  * the unsplit contig's. */
 #define NTEDIT_SEG_NO_HEADER 1u  /* not the first segment of its contig: no ">name" line                  */
@@ -254,6 +254,11 @@ typedef struct ntedit_hip_segment
 /* where the serial run of every entry's last applied event ended (entry-relative position; 0 = the entry
  * has no applied event).  A segment with a halo is valid iff cover_end <= lens[i] - halo. */
 int ntedit_hip_result_cover_ends(const ntedit_hip_result* r, uint32_t n_contigs, uint32_t* cover_ends);
+/* ok[i] = 1 iff write_outputs_ex() will accept entry i with segments[i] (the renderer's own predicate, evaluated
+ * from the edit records without rendering: the last applied event ended at or before the cut, the rope was not
+ * terminated and ends in the open position node, which starts in front of the cut).  Check BEFORE writing: an entry
+ * that fails is polished again joined with its successor. */
+int ntedit_hip_result_cuts_ok(const ntedit_hip_result* r, uint32_t n_contigs, const uint32_t* lens, const ntedit_hip_segment* segments, uint8_t* ok);
 
 /* ---- edit records (the reference's per-contig rope + substitution queue, sRec / seqNode,
  * ntedit.cpp:599-620, flattened the way writeEditsToFile walks them, ntedit.cpp:936-1212) -------------
@@ -327,6 +332,30 @@ float ntedit_hip_last_kernel_ms(const ntedit_hip_ctx* ctx);
 /* random 1-byte gather micro-benchmark over a filter-sized buffer: the
  * "HBM random-read roofline" denominator of SURVEY.md 8(d).  Returns probes/s. */
 int ntedit_hip_gather_bench(ntedit_hip_ctx* ctx, uint64_t nbytes, uint64_t n_probes, double* probes_per_s, float* ms);
+
+/* ---- draft ingest (replaces kseq as used by readAndCorrect, ntedit.cpp:2213-2234; lib/kseq.h:176-215) ------------
+ * Reads a whole FASTA / FASTQ draft (plain, gzip or BGZF -- told apart by their magic bytes) with the host binary's
+ * readers and keeps the records with >= min_len bases (-z, ntedit.cpp:2242) as ONE buffer in the batch layout of
+ * ntedit_hip_polish_batch: every sequence followed by '\n'.  header = name [+ " " + comment] (ntedit.cpp:2224-2229).
+ * err (may be NULL) receives a message when the file cannot be opened or turns out to be corrupt / truncated
+ * half-way (NTEDIT_E_IO; kseq would stop silently).  threads 0 = default. */
+typedef struct ntedit_hip_fasta ntedit_hip_fasta;
+int ntedit_hip_fasta_load(const char* path, uint64_t min_len, unsigned threads, ntedit_hip_fasta** out, char* err, size_t errcap);
+uint64_t ntedit_hip_fasta_count(const ntedit_hip_fasta* f);
+const char* ntedit_hip_fasta_blob(const ntedit_hip_fasta* f, uint64_t* nbytes);
+int ntedit_hip_fasta_record(const ntedit_hip_fasta* f, uint64_t i, const char** header, uint64_t* header_len, uint64_t* offset, uint64_t* len);
+void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
+
+/* Test and tuning knobs (not part of the reference surface).  NONE of them can change a result: they pick between
+ * implementations that are bit-identical by construction (and tested to be), split work differently, or print
+ * timings.  Keys: "screen_mode" (overrides params.screen_mode), "bin_chunk" (k-mer starts per record chunk of the
+ * partitioned screening), "bin_cap_percent" (record-run capacity in percent of the expectation: forces the overflow
+ * list), "bin_fallback" (1: direct kernel from now on, as after a lost overflow), "force_xcc" (x + 1: the probe
+ * stage behaves as if every wavefront ran on XCD x), "bin_timing", "chunk_bytes" (pipeline chunk size), "h2d_piece"
+ * (bytes per host-to-device piece), "inline_tries", "screen_lds_pad", "no_rounds", "no_early_copy", "no_lds_ws".
+ * The library reads two environment variables only: NTEDIT_HIP_DEBUG (diagnostics on stderr) and
+ * NTEDIT_HIP_NO_BIND (see ntedit_hip_bind_near_device). */
+int ntedit_hip_set_tuning(ntedit_hip_ctx* ctx, const char* key, uint64_t value);
 
 #ifdef __cplusplus
 }

@@ -91,9 +91,24 @@ struct ntedit_hip_ctx
 	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters, deferred;
 	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps, ws_win;
 	DevBuf offs, lens;
-	DevBuf bin_records, bin_bases, bin_work, wc_counts, wc_wbase;
+	DevBuf bin_records, bin_fill, bin_ctl, bin_ovf, bin_lost;
+	bool bin_fallback = false;        // an overflow list overflowed: this context screens with the direct kernel from now on
+	struct Tuning                     // ntedit_hip_set_tuning(): test / tuning knobs, none of which can change a result
+	{
+		u32 screen_mode = 0;     // overrides params.screen_mode when not 0
+		u64 bin_chunk = 0;       // k-mer starts per record chunk of the binned screening (tests: several chunks)
+		u32 bin_cap_percent = 0; // run capacity in percent of the expected records (tests: force the overflow list)
+		u32 force_xcc = 0;       // x + 1: every probe wavefront pretends to run on XCD x (tests)
+		u32 bin_timing = 0;      // per-stage times of the binned screening on stderr
+		u64 chunk_bytes = 0;     // pipeline chunk size (tests: many chunks)
+		u64 h2d_piece = ~0ULL;   // bytes per host-to-device piece (~0: default)
+		u32 inline_tries = ~0u;  // candidates of an indel sweep the deferring launch tries itself (~0: default)
+		u32 screen_lds_pad = 0;  // LDS pad of the direct screening kernel (occupancy experiments)
+		u32 no_rounds = 0, no_early_copy = 0, no_lds_ws = 0;
+	} tune;
 	DevBuf ev_cover, ev_before, ev_flags, ev_list, ev_bmax; // event rounds
 	u32 cu_count = 256;
+	size_t lds_per_block = 160 * 1024;
 	std::vector<PinBuf> pin_pool;
 	std::mutex pin_mu;
 };
@@ -249,11 +264,13 @@ refresh_params(ntedit_hip_ctx* c)
 	if (rc) {
 		return fail(c, rc, "unsupported parameter combination (k=%u h=%u)", f.k, f.hash_num);
 	}
+#ifdef NTE_ABLATION
 	if (const char* e = getenv("NTEDIT_HIP_MACHINE_DEBUG")) {
-		c->dp.debug_stop = (u32)atoi(e); // timing ablations; results are NOT valid
+		c->dp.debug_stop = (u32)atoi(e); // timing ablations; results are NOT valid (ablation build only)
 	}
-	if (const char* e = getenv("NTEDIT_HIP_INLINE_TRIES")) { // tuning / tests (any value gives the same results)
-		c->dp.inline_tries = (u32)atoi(e);
+#endif
+	if (c->tune.inline_tries != ~0u) { // tuning / tests (any value gives the same results)
+		c->dp.inline_tries = c->tune.inline_tries;
 	}
 	if (!c->d_tab) {
 		HIP_TRY(c, hipMalloc((void**)&c->d_tab, TAB_WORDS * sizeof(u64)));
@@ -269,6 +286,7 @@ refresh_params(ntedit_hip_ctx* c)
 }
 
 bool binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_log2, u32* n_slices);
+int bin_records_lost(ntedit_hip_ctx* c, bool* lost);
 int run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d_bitmap, u64 n_words, u32 slog, u32 n_slices, hipStream_t stream = nullptr, u64 pos_begin = 0, u64 pos_end = ~0ULL);
 
 // Launches k_screen over tiles [first_tile, first_tile + n_tiles) of the batch on `stream`.
@@ -296,8 +314,8 @@ launch_screen_tiles(
 	}
 	dim3 grid((unsigned)n_tiles), block(SCREEN_TPB);
 	const bool pow2 = f.mask != 0;
-	if (const char* e = getenv("NTEDIT_HIP_SCREEN_LDS_PAD")) { // tuning hook
-		lds_pad = (size_t)strtoull(e, nullptr, 10);
+	if (c->tune.screen_lds_pad) { // tuning
+		lds_pad = c->tune.screen_lds_pad;
 	}
 #define NTE_LAUNCH(H)                                                                            \
 	do {                                                                                         \
@@ -363,11 +381,8 @@ launch_screen(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u64* d
 bool
 binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_log2, u32* n_slices)
 {
-	u32 mode = c->hp.screen_mode;
-	if (const char* e = getenv("NTEDIT_HIP_SCREEN_MODE")) { // test hook (the fuzz forces the pipeline on small cases)
-		mode = (u32)atoi(e);
-	}
-	if (mode == 1 || f.hash_num == 0 || f.hash_num > 5 || f.counting || c->hp.snv) {
+	u32 mode = c->tune.screen_mode ? c->tune.screen_mode : c->hp.screen_mode;
+	if (mode == 1 || c->bin_fallback || f.hash_num == 0 || f.hash_num > 5 || f.counting || c->hp.snv) {
 		return false;
 	}
 	u32 slog = 24; // 2 MiB slices while the filter has at most WC_MAX_SLICES of them, 4 / 8 MiB beyond
@@ -376,7 +391,7 @@ binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_lo
 		slog++;
 		ns = (f.bits + (1ULL << slog) - 1) >> slog;
 	}
-	if (slog > 26) {
+	if (slog > 26 || n >= (1ULL << (63 - slog)) || wc_lds_bytes(c->dp.k) + 1024 > c->lds_per_block) {
 		return false; // slices beyond 8 MiB do not stay in an XCD's 4 MiB L2 long enough to matter
 	}
 	*slice_log2 = slog;
@@ -387,53 +402,94 @@ binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_lo
 	return f.bits >= (1ULL << 30) && n >= (1ULL << 26); // auto: filters >= 128 MiB, batches >= 64 Mbases
 }
 
+// The binned screening of this context lost probe records (an overflow list overflowed: a draft made of very few
+// distinct k-mers): its bitmap is void.  From then on the context screens with the direct kernel; the caller runs
+// the screening again.  (Streams must be idle.)
+int
+bin_records_lost(ntedit_hip_ctx* c, bool* lost)
+{
+	*lost = false;
+	if (!c->bin_lost.p || !c->bin_chunks_last) {
+		return 0;
+	}
+	u32 v = 0;
+	HIP_TRY(c, hipMemcpy(&v, c->bin_lost.p, 4, hipMemcpyDeviceToHost));
+	if (v) {
+		HIP_TRY(c, hipMemset(c->bin_lost.p, 0, 4));
+		c->bin_fallback = true;
+		*lost = true;
+	}
+	return 0;
+}
+
+// geometry of one record chunk: runs of `cap` records, one per (slice, partition workgroup) pair
+struct WcPlan
+{
+	u32 n_wg;
+	u32 cap;
+	u64 n_wtiles;
+	u64 record_bytes;
+};
+
+WcPlan
+plan_wc(const ntedit_hip_ctx* c, u64 kmers, u32 hash_num, u32 n_slices)
+{
+	WcPlan w;
+	w.n_wtiles = (kmers + WC_WTILE - 1) / WC_WTILE;
+	const u64 per_wg_tiles = WC_WAVES; // a workgroup below that would idle wavefronts
+	u64 n_wg = (w.n_wtiles + per_wg_tiles - 1) / per_wg_tiles;
+	if (n_wg > c->cu_count) {
+		n_wg = c->cu_count; // persistent workgroups, one per CU (the rings take nearly all of a CU's LDS)
+	}
+	if (n_wg == 0) {
+		n_wg = 1;
+	}
+	w.n_wg = (u32)n_wg;
+	// records a pair can expect: the k-mer starts of its workgroup's wavefront tiles, h probes each, spread evenly
+	// over the slices (the hash values of distinct k-mers are uniform); 6 sigma + a group on top.  What exceeds the
+	// run (repeated k-mers: their probes all meet the same slices) goes to the overflow list.
+	const u64 tiles_per_wg = (w.n_wtiles + (u64)w.n_wg * WC_WAVES - 1) / ((u64)w.n_wg * WC_WAVES) * WC_WAVES;
+	const double mean = (double)tiles_per_wg * WC_WTILE * hash_num / (double)n_slices;
+	double cap = mean + 6.0 * sqrt(mean) + 64.0;
+	if (c->tune.bin_cap_percent) {
+		cap = mean * c->tune.bin_cap_percent / 100.0 + 8.0; // tests: force the overflow path
+	}
+	u64 capi = ((u64)cap + WC_GROUP - 1) / WC_GROUP * WC_GROUP;
+	if (capi > WC_MAX_RUN) {
+		capi = WC_MAX_RUN; // (what does not fit goes through the overflow list)
+	}
+	w.cap = (u32)capi;
+	w.record_bytes = (u64)n_slices * w.n_wg * w.cap * 8;
+	return w;
+}
+
 template<int H, bool POW2>
 int
-launch_wc(ntedit_hip_ctx* c, hipStream_t stream, const WcArgs& w, u64 tiles)
+launch_wc(ntedit_hip_ctx* c, hipStream_t stream, const WcArgs& w)
 {
-	static bool attr_set = false;
-	if (!attr_set) {
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wc_scatter<H, POW2>),
-		                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_LDS_BYTES));
-		attr_set = true;
-	}
-	hipLaunchKernelGGL((k_wc_count<H, POW2>), dim3((unsigned)tiles), dim3(SCREEN_TPB), 0, stream, w);
-	hipLaunchKernelGGL(k_wc_scan, dim3(1), dim3(1024), 0, stream, (const u32*)w.counts, w.n_wg, w.b.n_slices, w.wbase,
-	                   (unsigned long long*)c->bin_bases.p);
-	hipLaunchKernelGGL((k_wc_scatter<H, POW2>), dim3(w.n_wg), dim3(WC_TPB), WC_LDS_BYTES, stream, w);
+	// (per device: the attribute belongs to the function ON the current device)
+	const size_t lds = wc_lds_bytes(w.b.p.k);
+	HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wc_scatter<H, POW2>),
+	                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL((k_wc_scatter<H, POW2>), dim3(w.n_wg), dim3(WC_TPB), lds, stream, w);
 	return 0;
 }
 
 int
-run_wc_partition(ntedit_hip_ctx* c, hipStream_t stream, const BinArgs& a, u64 tiles)
+run_wc_partition(ntedit_hip_ctx* c, hipStream_t stream, const WcArgs& w)
 {
-	WcArgs w;
-	w.b = a;
-	w.n_wg = c->cu_count; // persistent workgroups, one per CU (the rings take nearly all of a CU's LDS)
-	if ((u64)w.n_wg > tiles) {
-		w.n_wg = (u32)tiles;
-	}
-	w.n_tiles = (u32)tiles;
-	int rc;
-	const size_t cells = (size_t)w.n_wg * a.n_slices;
-	if ((rc = ensure(c, c->wc_counts, cells * 4)) || (rc = ensure(c, c->wc_wbase, cells * 4))) {
-		return rc;
-	}
-	w.counts = (u32*)c->wc_counts.p;
-	w.wbase = (u32*)c->wc_wbase.p;
-	HIP_TRY(c, hipMemsetAsync(w.counts, 0, cells * 4, stream));
-	const bool pow2 = a.f.mask != 0;
-	switch (a.f.hash_num) {
+	const bool pow2 = w.b.f.mask != 0;
+	switch (w.b.f.hash_num) {
 	case 1:
-		return pow2 ? launch_wc<1, true>(c, stream, w, tiles) : launch_wc<1, false>(c, stream, w, tiles);
+		return pow2 ? launch_wc<1, true>(c, stream, w) : launch_wc<1, false>(c, stream, w);
 	case 2:
-		return pow2 ? launch_wc<2, true>(c, stream, w, tiles) : launch_wc<2, false>(c, stream, w, tiles);
+		return pow2 ? launch_wc<2, true>(c, stream, w) : launch_wc<2, false>(c, stream, w);
 	case 3:
-		return pow2 ? launch_wc<3, true>(c, stream, w, tiles) : launch_wc<3, false>(c, stream, w, tiles);
+		return pow2 ? launch_wc<3, true>(c, stream, w) : launch_wc<3, false>(c, stream, w);
 	case 4:
-		return pow2 ? launch_wc<4, true>(c, stream, w, tiles) : launch_wc<4, false>(c, stream, w, tiles);
+		return pow2 ? launch_wc<4, true>(c, stream, w) : launch_wc<4, false>(c, stream, w);
 	default:
-		return pow2 ? launch_wc<5, true>(c, stream, w, tiles) : launch_wc<5, false>(c, stream, w, tiles);
+		return pow2 ? launch_wc<5, true>(c, stream, w) : launch_wc<5, false>(c, stream, w);
 	}
 }
 
@@ -446,60 +502,80 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 	if (pos_end > n) {
 		pos_end = n;
 	}
-	// chunks: fewer than 2^32 records each (32-bit record indices), at most 2^30 k-mer starts, and a record
-	// buffer that takes no more than a quarter of the HBM that is free right now
-	u64 chunk = ((1ULL << 32) - (1ULL << 22)) / f.hash_num;
-	if (chunk > (1ULL << 30)) {
-		chunk = 1ULL << 30;
-	}
-	if (c->bin_records.cap < chunk * f.hash_num * 8) {
+	const u64 span = pos_end - pos_begin;
+	// record chunks: the whole range at once when its records take no more than 40 % of the HBM that is free right
+	// now (3 Gbp at h = 3: 76 GB), else as few equal chunks as that allows
+	const u64 unit = (u64)WC_WTILE * WC_WAVES; // chunk sizes: whole workgroup rounds (also a multiple of 16 bytes)
+	u64 chunk = (span + unit - 1) / unit * unit;
+	{
 		size_t free_b = 0, total_b = 0;
+		u64 room = ~0ULL;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-			const u64 room = (u64)(free_b + c->bin_records.cap) / 4 / ((u64)f.hash_num * 8);
-			if (room < chunk) {
-				chunk = room;
-			}
+			room = (u64)(free_b + c->bin_records.cap) * 2 / 5;
+		}
+		u64 parts = 1;
+		while (parts < 4096 && plan_wc(c, (span + parts - 1) / parts, f.hash_num, n_slices).record_bytes > room) {
+			parts++;
+		}
+		if (parts > 1) {
+			chunk = ((span + parts - 1) / parts + unit - 1) / unit * unit;
+		}
+		if (plan_wc(c, chunk, f.hash_num, n_slices).record_bytes > room) {
+			return fail(c, NTEDIT_E_DEVICE, "not enough device memory for the screening records");
 		}
 	}
-	if (const char* e = getenv("NTEDIT_HIP_BIN_CHUNK")) { // test hook: force several chunks
-		const u64 v = strtoull(e, nullptr, 10);
-		if (v >= (u64)SCREEN_TILE && v < chunk) {
+	if (c->tune.bin_chunk) { // tests: force several chunks
+		const u64 v = c->tune.bin_chunk / unit * unit;
+		if (v >= unit && v < chunk) {
 			chunk = v;
 		}
 	}
-	chunk = chunk / SCREEN_TILE * SCREEN_TILE;
-	if (chunk == 0) {
-		return fail(c, NTEDIT_E_DEVICE, "not enough device memory for the screening records");
-	}
-	const u64 span = pos_end - pos_begin;
-	const u64 first_chunk = span < chunk ? (span + SCREEN_TILE - 1) / SCREEN_TILE * SCREEN_TILE : chunk;
+	const WcPlan plan0 = plan_wc(c, span < chunk ? span : chunk, f.hash_num, n_slices);
+	const u32 ovf_cap = 1u << 22; // 64 MiB of overflow entries per chunk; beyond that the direct kernel takes over
+	const size_t ctl_words = CTL_WORK + (size_t)n_slices + 1;
 	int rc;
-	if ((rc = ensure(c, c->bin_records, first_chunk * f.hash_num * 8)) ||
-	    (rc = ensure(c, c->bin_bases, (size_t)(n_slices + 1) * 8)) ||
-	    (rc = ensure(c, c->bin_work, (size_t)(n_slices + 1) * 4))) {
+	if (!c->bin_lost.p) {
+		if ((rc = ensure(c, c->bin_lost, 4))) {
+			return rc;
+		}
+		HIP_TRY(c, hipMemsetAsync(c->bin_lost.p, 0, 4, stream));
+	}
+	if ((rc = ensure(c, c->bin_records, plan0.record_bytes)) ||
+	    (rc = ensure(c, c->bin_fill, (size_t)n_slices * plan0.n_wg * 4)) ||
+	    (rc = ensure(c, c->bin_ctl, (ctl_words + 1) * 4)) ||
+	    (rc = ensure(c, c->bin_ovf, (size_t)ovf_cap * sizeof(WcOvf)))) {
 		return rc;
 	}
+	u32* d_ctl = (u32*)c->bin_ctl.p;
+	u32* d_ovf_count = d_ctl + ctl_words;
 	{
 		// the probe stage ORs into the bitmap: clear the words of the range first
 		const u64 w0 = pos_begin / 64, w1 = (pos_end + 63) / 64 < n_words ? (pos_end + 63) / 64 : n_words;
 		HIP_TRY(c, hipMemsetAsync(d_bitmap + w0, 0, (w1 - w0) * 8, stream));
 	}
-	const bool timing = getenv("NTEDIT_HIP_BIN_TIMING") != nullptr; // experiments: per-stage times on stderr
 	u32 chunk_no = 0;
 	for (u64 begin = pos_begin; begin < pos_end; begin += chunk, chunk_no++) {
 		const u64 end = begin + chunk < pos_end ? begin + chunk : pos_end;
-		const u64 blocks = (end - begin + SCREEN_TILE - 1) / SCREEN_TILE;
-		BinArgs a;
-		a.seq = d_seq;
-		a.n = n;
-		a.chunk_begin = begin;
-		a.chunk_end = end;
-		a.f = f;
-		a.p = c->dp;
-		a.tabs = c->d_tab;
-		a.n_slices = n_slices;
-		a.slice_log2 = slog;
-		a.records = (u64*)c->bin_records.p;
+		const WcPlan plan = plan_wc(c, end - begin, f.hash_num, n_slices);
+		WcArgs w;
+		w.b.seq = d_seq;
+		w.b.n = n;
+		w.b.chunk_begin = begin;
+		w.b.chunk_end = end;
+		w.b.f = f;
+		w.b.p = c->dp;
+		w.b.tabs = c->d_tab;
+		w.b.n_slices = n_slices;
+		w.b.slice_log2 = slog;
+		w.b.records = (u64*)c->bin_records.p;
+		w.fill = (u32*)c->bin_fill.p;
+		w.ovf = (WcOvf*)c->bin_ovf.p;
+		w.ovf_count = d_ovf_count;
+		w.ovf_cap = ovf_cap;
+		w.n_wg = plan.n_wg;
+		w.cap = plan.cap;
+		w.n_wtiles = plan.n_wtiles;
+		w.wcodes = (u32)wc_codes_bytes(c->dp.k);
 		while (c->bin_ev.size() < 3 * (size_t)(chunk_no + 1)) {
 			hipEvent_t e;
 			HIP_TRY(c, hipEventCreate(&e));
@@ -514,24 +590,39 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 			}
 			HIP_TRY(c, hipStreamWaitEvent(stream, c->h2d_ev[piece], 0));
 		}
-		HIP_TRY(c, hipMemsetAsync(c->bin_work.p, 0, (size_t)(n_slices + 1) * 4, stream));
+		HIP_TRY(c, hipMemsetAsync(d_ctl, 0, (ctl_words + 1) * 4, stream));
 		HIP_TRY(c, hipEventRecord(tev[0], stream));
-		if ((rc = run_wc_partition(c, stream, a, blocks))) {
+		if ((rc = run_wc_partition(c, stream, w))) {
 			return rc;
 		}
 		HIP_TRY(c, hipEventRecord(tev[1], stream));
-		hipLaunchKernelGGL(
-		    k_bin_probe, dim3(c->cu_count * 8), dim3(PROBE_TPB), 0, stream, f.data, (const u64*)c->bin_records.p,
-		    (const unsigned long long*)c->bin_bases.p, n_slices, slog, (u32*)c->bin_work.p, (u32*)d_bitmap);
+		ProbeArgs pa;
+		pa.filter = f.data;
+		pa.records = (const u64*)c->bin_records.p;
+		pa.fill = (const u32*)c->bin_fill.p;
+		pa.n_slices = n_slices;
+		pa.slog = slog;
+		pa.n_wg = plan.n_wg;
+		pa.cap = plan.cap;
+		pa.ctl = d_ctl;
+		pa.absent32 = (u32*)d_bitmap;
+		pa.force_xcc = c->tune.force_xcc ? c->tune.force_xcc - 1 : PROBE_XCC_ANY;
+		hipLaunchKernelGGL(k_bin_probe, dim3(c->cu_count * 8), dim3(PROBE_TPB), 0, stream, pa);
+		hipLaunchKernelGGL(k_ovf_probe, dim3(64), dim3(256), 0, stream, f.data, (const WcOvf*)c->bin_ovf.p, (const u32*)d_ovf_count, ovf_cap, slog,
+		                   (u32*)d_bitmap);
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipEventRecord(tev[2], stream));
-		if (timing) {
+		// overflow entries that did not fit are lost probes: the caller must look at this before it trusts the bitmap
+		hipLaunchKernelGGL(k_ovf_check, dim3(1), dim3(1), 0, stream, (const u32*)d_ovf_count, ovf_cap, (u32*)c->bin_lost.p);
+		if (c->tune.bin_timing) {
 			HIP_TRY(c, hipStreamSynchronize(stream));
 			float t_part = 0.f, t_probe = 0.f;
 			(void)hipEventElapsedTime(&t_part, tev[0], tev[1]);
 			(void)hipEventElapsedTime(&t_probe, tev[1], tev[2]);
-			fprintf(stderr, "[ntedit_hip] binned chunk %llu k-mers, %u slices of 2^%u bits: partition %.3f ms, probe %.3f ms\n",
-			        (unsigned long long)(end - begin), n_slices, slog, t_part, t_probe);
+			u32 ovf_n = 0;
+			(void)hipMemcpy(&ovf_n, d_ovf_count, 4, hipMemcpyDeviceToHost);
+			fprintf(stderr, "[ntedit_hip] binned chunk %llu k-mers, %u slices of 2^%u bits, %u x %u-record runs per slice (%.2f GB), %u overflow records: partition %.3f ms, probe %.3f ms\n",
+			        (unsigned long long)(end - begin), n_slices, slog, plan.n_wg, plan.cap, plan.record_bytes / 1e9, ovf_n, t_part, t_probe);
 		}
 	}
 	c->bin_chunks_last = chunk_no;
@@ -599,6 +690,10 @@ ntedit_hip_create(int device, ntedit_hip_ctx** out)
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
 		c->cu_count = (u32)prop.multiProcessorCount;
+		int lds = 0;
+		if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess && lds > 0) {
+			c->lds_per_block = (size_t)lds;
+		}
 	}
 	if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess) {
 		delete c;
@@ -642,7 +737,7 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 	}
 	DevBuf* bufs[] = { &c->seq,      &c->bitmap,   &c->block_counts, &c->block_offsets, &c->events,
 		               &c->first_chunk, &c->arena, &c->counters, &c->deferred,     &c->ws_nodes,      &c->ws_ov_pos,
-		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->bin_records, &c->bin_bases, &c->bin_work, &c->wc_counts, &c->wc_wbase, &c->ev_cover, &c->ev_before, &c->ev_flags, &c->ev_list, &c->ev_bmax,       &c->offs,          &c->lens };
+		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->bin_records, &c->bin_fill, &c->bin_ctl, &c->bin_ovf, &c->bin_lost, &c->ev_cover, &c->ev_before, &c->ev_flags, &c->ev_list, &c->ev_bmax,       &c->offs,          &c->lens };
 	for (DevBuf* b : bufs) {
 		release(*b);
 	}
@@ -1030,16 +1125,25 @@ ntedit_hip_screen(ntedit_hip_ctx* c, const char* bases, uint64_t n, int on_devic
 		}
 		d_bitmap = (u64*)c->bitmap.p;
 	}
-	HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-	rc = launch_screen<false>(c, d_seq, n, dev_filter(c->filt[0]), d_bitmap, n_words);
-	if (rc) {
-		return rc;
+	for (;;) {
+		HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+		rc = launch_screen<false>(c, d_seq, n, dev_filter(c->filt[0]), d_bitmap, n_words);
+		if (rc) {
+			return rc;
+		}
+		HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		bool lost = false;
+		if ((rc = bin_records_lost(c, &lost))) {
+			return rc;
+		}
+		if (!lost) {
+			break;
+		}
 	}
-	HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
 	if (!on_device) {
-		HIP_TRY(c, hipMemcpyAsync(bitmap, d_bitmap, n_words * 8, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(c, hipMemcpy(bitmap, d_bitmap, n_words * 8, hipMemcpyDeviceToHost));
 	}
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev[0], c->ev[1]));
 	return 0;
 }
@@ -1142,8 +1246,8 @@ PolishRun::plan()
 	// (ntedit_hip_host_alloc, or any hipHostMalloc / registered memory) copy asynchronously at link speed;
 	// pageable ones are staged by the runtime, the overlap is the same.
 	h2d_piece = 128ull << 20;
-	if (const char* e = getenv("NTEDIT_HIP_H2D_PIECE")) { // tests / tuning: bytes per piece (0 = one copy up front)
-		h2d_piece = strtoull(e, nullptr, 10) / SCREEN_TILE * SCREEN_TILE;
+	if (c->tune.h2d_piece != ~0ULL) { // tests / tuning: bytes per piece (0 = one copy up front)
+		h2d_piece = c->tune.h2d_piece / SCREEN_TILE * SCREEN_TILE;
 	}
 	h2d_overlap = !on_device && h2d_piece > 0 && n > 2 * h2d_piece;
 	if ((rc = stage_bases(c, bases, n, on_device, &d_seq, !h2d_overlap))) {
@@ -1170,11 +1274,8 @@ PolishRun::plan()
 		// default is a single chunk; the chunk pipeline stays available (and tested) for
 		// bounded-memory operation.
 		u64 target = n + 1;
-		if (const char* e = getenv("NTEDIT_HIP_CHUNK_BYTES")) { // test hook: force many chunks
-			const u64 v = strtoull(e, nullptr, 10);
-			if (v > 0) {
-				target = v;
-			}
+		if (c->tune.chunk_bytes) { // tests: force many chunks
+			target = c->tune.chunk_bytes;
 		}
 		u32 c0 = 0;
 		u64 t_prev = 0;
@@ -1348,7 +1449,7 @@ PolishRun::launch_wave_pass(MachineArgs a, const u32* list, u32 count)
 	const u64 w16 = (Wn + 15) & ~15ull;
 	const u64 slab = Wn * 16 + w16 * 4 + w16 * 2 + w16 + w16;
 	const u64 win_area = ((u64)a.win_bytes * per_block + 15) & ~15ull;
-	if (win_area + slab * per_block <= 40 * 1024 && !getenv("NTEDIT_HIP_NO_LDS_WS")) {
+	if (win_area + slab * per_block <= 40 * 1024 && !c->tune.no_lds_ws) {
 		a.win_in_lds = 1;
 		a.lds_ws_off = (u32)win_area;
 		a.lds_slab = (u32)slab;
@@ -1482,7 +1583,7 @@ PolishRun::run_chunk_events(size_t j)
 	// ---- rounds (see "event rounds" in nte_kernels.hip): primaries, then the secondaries their
 	// primary's run does not overtake, then -- practically never -- whatever a verification rejects.
 	// Pipeline chunks and SNV mode run everything in one round.
-	const bool rounds = n_ch == 1 && !c->dp.snv && n_ev < 0xFFFFFF00ull && !getenv("NTEDIT_HIP_NO_ROUNDS");
+	const bool rounds = n_ch == 1 && !c->dp.snv && n_ev < 0xFFFFFF00ull && !c->tune.no_rounds;
 	u32* d_list = nullptr;
 	u64* d_before = nullptr;
 	u64* d_bmax = nullptr;
@@ -1527,7 +1628,7 @@ PolishRun::run_chunk_events(size_t j)
 		const u32 nd = h_tail[3];
 		n_def += nd;
 		status = h_tail[2];
-		if (first_round && nd > 0 && status == 0 && n_ch == 1 && !getenv("NTEDIT_HIP_NO_EARLY_COPY")) {
+		if (first_round && nd > 0 && status == 0 && n_ch == 1 && !c->tune.no_early_copy) {
 			// everything pass 1 wrote is final (later launches only append chunks): start moving it
 			// to the host on the other stream while the sweeps run
 			early_chunks = h_tail[0] < arena_chunks ? h_tail[0] : arena_chunks;
@@ -1542,9 +1643,11 @@ PolishRun::run_chunk_events(size_t j)
 		}
 		if (nd > 0 && status == 0) {
 			MachineArgs a2 = ra;
+#ifdef NTE_ABLATION
 			if (const char* dbg = getenv("NTEDIT_HIP_PASS2_DEBUG")) {
-				a2.p.debug_stop = (u32)atoi(dbg); // timing ablations; results are NOT valid
+				a2.p.debug_stop = (u32)atoi(dbg); // timing ablations; results are NOT valid (ablation build only)
 			}
+#endif
 			launch_wave_pass(a2, (const u32*)c->deferred.p, nd);
 			HIP_TRY(c, hipGetLastError());
 			HIP_TRY(c, hipEventRecord(c->ev[2], sB));
@@ -1840,6 +1943,15 @@ ntedit_hip_polish_batch(
 		if (hipStreamSynchronize(run.sA) != hipSuccess || hipStreamSynchronize(run.sB) != hipSuccess) {
 			return run.bail(fail(c, NTEDIT_E_DEVICE, "stream synchronisation failed: %s", hipGetErrorString(hipGetLastError())));
 		}
+		{
+			bool lost = false;
+			if ((rc = bin_records_lost(c, &lost))) {
+				return run.bail(rc);
+			}
+			if (lost && attempt < 4) {
+				continue; // (the context screens with the direct kernel now)
+			}
+		}
 		if (run.status == 0) {
 			bool redo = false;
 			if ((rc = run.collect(&redo))) {
@@ -2055,6 +2167,22 @@ ntedit_hip_result_cover_ends(const ntedit_hip_result* r, uint32_t n_contigs, uin
 }
 
 int
+ntedit_hip_result_cuts_ok(const ntedit_hip_result* r, uint32_t n_contigs, const uint32_t* lens, const ntedit_hip_segment* segments, uint8_t* ok)
+{
+	if (!r || (n_contigs && (!lens || !segments || !ok))) {
+		return NTEDIT_E_ARG;
+	}
+	std::vector<u32> halos(n_contigs);
+	for (u32 i = 0; i < n_contigs; i++) {
+		halos[i] = segments[i].halo;
+	}
+	return nte_host::cuts_ok((const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p, r->n_ev_first, n_contigs, lens,
+	                         halos.data(), ok)
+	           ? NTEDIT_E_ARG
+	           : 0;
+}
+
+int
 ntedit_hip_result_edits(
     ntedit_hip_result* r,
     const char* bases,
@@ -2225,6 +2353,47 @@ float
 ntedit_hip_last_kernel_ms(const ntedit_hip_ctx* c)
 {
 	return c ? c->last_ms : 0.f;
+}
+
+int
+ntedit_hip_set_tuning(ntedit_hip_ctx* c, const char* key, uint64_t value)
+{
+	if (!c || !key) {
+		return fail(c, NTEDIT_E_ARG, "set_tuning: bad argument");
+	}
+	const std::string k(key);
+	auto& t = c->tune;
+	if (k == "screen_mode") {
+		t.screen_mode = (u32)value;
+	} else if (k == "bin_chunk") {
+		t.bin_chunk = value;
+	} else if (k == "bin_cap_percent") {
+		t.bin_cap_percent = (u32)value;
+	} else if (k == "force_xcc") {
+		t.force_xcc = (u32)value;
+	} else if (k == "bin_timing") {
+		t.bin_timing = (u32)value;
+	} else if (k == "chunk_bytes") {
+		t.chunk_bytes = value;
+	} else if (k == "h2d_piece") {
+		t.h2d_piece = value;
+	} else if (k == "inline_tries") {
+		t.inline_tries = (u32)value;
+		c->dp_valid = false;
+	} else if (k == "screen_lds_pad") {
+		t.screen_lds_pad = (u32)value;
+	} else if (k == "no_rounds") {
+		t.no_rounds = (u32)value;
+	} else if (k == "no_early_copy") {
+		t.no_early_copy = (u32)value;
+	} else if (k == "no_lds_ws") {
+		t.no_lds_ws = (u32)value;
+	} else if (k == "bin_fallback") {
+		c->bin_fallback = value != 0;
+	} else {
+		return fail(c, NTEDIT_E_ARG, "set_tuning: unknown key '%s'", key);
+	}
+	return 0;
 }
 
 int

@@ -248,6 +248,9 @@ k_screen(
 //                  bit into the absent bitmap
 // Records are 8 bytes: (global k-mer position << slice_log2) | bit offset in slice.
 // Measured (MI355X, 3 Gbp, 4 GiB filter, h = 3): 116-121 ms against 176 ms for the direct kernel.
+constexpr u64 WC_EMPTY_REC = ~0ULL;             // padding of a run's last 64-byte group: no record
+constexpr u64 WC_REC_POS_MASK = ~(1ULL << 63);  // bit 63 of a stored record is the ring generation bit
+
 struct BinArgs
 {
 	const u8* seq;
@@ -259,73 +262,155 @@ struct BinArgs
 	const u64* tabs;
 	u32 n_slices;
 	u32 slice_log2;  // log2(bits per slice)
-	u64* records;    // < 2^32 records per chunk
+	u64* records;    // runs of `cap` records, one per (slice, partition workgroup) pair
 };
 
-// Every workgroup asks the hardware which XCD it runs on (HW_REG_XCC_ID) and serves the
-// slices {x, x+8, x+16, ...} of that XCD, pulling 1024-record pieces of the current slice
-// from a per-slice work counter.  All workgroups of an XCD therefore stay on the same
-// slice, whose 2 MiB of filter is fetched into that XCD's L2 once and then hit by all of
-// its records.  Placement only affects speed, never the result.
+// Probe stage.  A slice's 2-4 MiB of filter fit the 4 MiB L2 of ONE XCD, so all wavefronts of an XCD work on the
+// same slice at the same time: a wavefront asks the hardware which XCD it runs on (HW_REG_XCC_ID) and pulls
+// 512-record pieces of that XCD's CURRENT slice from the slice's piece counter.  Slices are not tied to XCDs: the
+// wavefront that draws the first piece index past the end of a slice takes the next unclaimed slice from a global
+// counter and publishes it as its XCD's current one.  Every slice is therefore probed completely whatever the number
+// of XCDs the device exposes (compute partitioning: 1, 2, 4 or 8), whichever of them receive workgroups, and
+// however fast each one is; placement only affects speed, never the result.
+// ctl[] (zeroed before the launch): [0] next unclaimed slice, [1..16] current slice of XCD x (0 = none yet,
+// 1 = being claimed, s + 2 = slice s), [32 + s] piece counter of slice s.
 constexpr int PROBE_TPB = 256;
-constexpr int PROBE_PIECE = PROBE_TPB * 4;
+constexpr int PROBE_PER = 8;                  // records per lane and step, all in flight together
+constexpr int PROBE_STEP = 64 * PROBE_PER;    // records per step of a wavefront
+#ifndef NTE_PROBE_STEPS
+#define NTE_PROBE_STEPS 8
+#endif
+constexpr int PROBE_PIECE = PROBE_STEP * NTE_PROBE_STEPS; // records per piece: one draw from the slice's counter (a counter
+                                                          // that every wavefront of an XCD draws from serves ~15 M draws/s)
+constexpr u32 CTL_NEXT = 0, CTL_CUR = 1, CTL_WORK = 32;
+constexpr u32 PROBE_XCC_ANY = 0xFFFFFFFFu;
+
+struct ProbeArgs
+{
+	const u8* filter;
+	const u64* records;
+	const u32* fill; // [n_slices][n_wg]
+	u32 n_slices;
+	u32 slog;
+	u32 n_wg;
+	u32 cap;
+	u32* ctl;
+	u32* absent32;
+	u32 force_xcc;   // PROBE_XCC_ANY, or the XCD id every wavefront pretends to run on (tests)
+};
 
 __device__ __forceinline__ u32
 xcc_id()
 {
 	// s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
-	return __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u;
+	return __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u;
+}
+
+__device__ __forceinline__ u32
+ctl_load(const u32* p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One lane: the next piece of the XCD's current slice, moving on to further slices as they run out.  `p` is a piece
+// index already drawn from slice `sl` (or sl == NONE32: nothing drawn yet).  Returns false when no slice is left.
+__device__ __forceinline__ bool
+probe_claim(u32* __restrict__ ctl, u32 xcd, u32 n_slices, u32 total, u32& sl, u32& p)
+{
+	u32* cur = ctl + CTL_CUR + xcd;
+	for (;;) {
+		if (sl != NONE32) {
+			if (p < total) {
+				return true;
+			}
+			if (p == total) {
+				// this draw closed the slice: open the next one for the whole XCD
+				const u32 nx = atomicAdd(&ctl[CTL_NEXT], 1u);
+				__hip_atomic_store(cur, nx + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+		// the XCD's current slice (another wavefront may be switching it right now)
+		u32 v = ctl_load(cur);
+		for (;;) {
+			if (v == 0) {
+				if (atomicCAS(cur, 0u, 1u) == 0u) {
+					const u32 nx = atomicAdd(&ctl[CTL_NEXT], 1u);
+					__hip_atomic_store(cur, nx + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			} else if (v >= 2 && v - 2 != sl) {
+				break;
+			} else {
+				__builtin_amdgcn_s_sleep(4);
+			}
+			v = ctl_load(cur);
+		}
+		sl = v - 2;
+		if (sl >= n_slices) {
+			return false;
+		}
+		p = atomicAdd(&ctl[CTL_WORK + sl], 1u);
+	}
 }
 
 __global__ __launch_bounds__(PROBE_TPB) void
-k_bin_probe(
-    const u8* __restrict__ filter,
-    const u64* __restrict__ records,
-    const unsigned long long* __restrict__ bases,
-    u32 n_slices,
-    u32 slog,
-    u32* __restrict__ work, // [n_slices] zeroed piece counters
-    u32* __restrict__ absent32)
+k_bin_probe(ProbeArgs a)
 {
-	__shared__ u32 s_piece;
-	const u64 off_mask = (1ULL << slog) - 1;
-	const u32 xcd = xcc_id();
-	for (u32 sl = xcd; sl < n_slices; sl += 8) {
-		const u64 lo = bases[sl], hi = bases[sl + 1];
-		const u8* fs = filter + ((u64)sl << (slog - 3));
-		while (true) {
-			__syncthreads();
-			if (threadIdx.x == 0) {
-				s_piece = atomicAdd(&work[sl], 1u);
+	const u32 lane = threadIdx.x & 63;
+	const u64 off_mask = (1ULL << a.slog) - 1;
+	const u32 xcd = a.force_xcc == PROBE_XCC_ANY ? xcc_id() : (a.force_xcc & 15u);
+	const u32 ppr = (a.cap + PROBE_PIECE - 1) / PROBE_PIECE; // pieces per run
+	const u32 total = a.n_wg * ppr;
+	u32 sl = NONE32, p = 0;
+	for (;;) {
+		{
+			u32 ok = 0;
+			if (lane == 0) {
+				ok = probe_claim(a.ctl, xcd, a.n_slices, total, sl, p) ? 1u : 0u;
 			}
-			__syncthreads();
-			const u64 i0 = lo + (u64)s_piece * PROBE_PIECE;
-			if (i0 >= hi) {
-				break;
+			ok = __builtin_amdgcn_readfirstlane(ok);
+			sl = __builtin_amdgcn_readfirstlane(sl);
+			p = __builtin_amdgcn_readfirstlane(p);
+			if (!ok) {
+				return;
 			}
-			u64 rec[4];
-			u8 byte[4];
+		}
+		// draw the piece after this one now: its round trip hides behind the probes
+		u32 pn = 0;
+		if (lane == 0) {
+			pn = atomicAdd(&a.ctl[CTL_WORK + sl], 1u);
+		}
+		const u32 w = p / ppr;
+		const u32 i0 = (p - w * ppr) * PROBE_PIECE;
+		const u32 fill = a.fill[(size_t)sl * a.n_wg + w];
+		if (i0 < fill) {
+			const u32 n = fill - i0 < (u32)PROBE_PIECE ? fill - i0 : (u32)PROBE_PIECE;
+			const u64* __restrict__ src = a.records + ((u64)(sl * a.n_wg + w) * a.cap + i0);
+			const u8* __restrict__ fs = a.filter + ((u64)sl << (a.slog - 3));
+			for (u32 s0 = 0; s0 < n; s0 += PROBE_STEP) {
+				u64 rec[PROBE_PER];
+				u8 byte[PROBE_PER];
 #pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const u64 i = i0 + (u64)q * PROBE_TPB + threadIdx.x;
-								// (non-temporal: the records are read once; the slice they probe should keep the XCD's L2 --
-				// 63.6 instead of 67.7 ms per 3 Gbp)
-				rec[q] = i < hi ? __builtin_nontemporal_load(records + i) : ~0ULL;
-			}
+				for (int q = 0; q < PROBE_PER; q++) {
+					const u32 i = s0 + (u32)q * 64 + lane;
+					// (non-temporal: the records are read once; the slice they probe should keep the XCD's L2)
+					rec[q] = i < n ? __builtin_nontemporal_load(src + i) : WC_EMPTY_REC;
+				}
 #pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const u32 off = (u32)(rec[q] & off_mask);
-				byte[q] = rec[q] != ~0ULL ? fs[off >> 3] : (u8)0xFF;
-			}
+				for (int q = 0; q < PROBE_PER; q++) {
+					const u32 off = (u32)(rec[q] & off_mask);
+					byte[q] = rec[q] != WC_EMPTY_REC ? fs[off >> 3] : (u8)0xFF;
+				}
 #pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const u32 off = (u32)(rec[q] & off_mask);
-				if (!((byte[q] >> (off & 7)) & 1)) {
-					const u64 pos = rec[q] >> slog;
-					atomicOr(&absent32[pos >> 5], 1u << (pos & 31));
+				for (int q = 0; q < PROBE_PER; q++) {
+					const u32 off = (u32)(rec[q] & off_mask);
+					if (!((byte[q] >> (off & 7)) & 1)) {
+						const u64 pos = (rec[q] & WC_REC_POS_MASK) >> a.slog;
+						atomicOr(&a.absent32[pos >> 5], 1u << (pos & 31));
+					}
 				}
 			}
 		}
+		p = pn;
 	}
 }
 

@@ -77,7 +77,8 @@ enum
 	OPT_REPORT,
 	OPT_START_GRID,
 	OPT_EVENT_BUDGET,
-	OPT_NO_MAP
+	OPT_NO_MAP,
+	OPT_TUNE
 };
 static const struct option longopts[] = {
 	{ "threads", required_argument, nullptr, 't' },
@@ -107,6 +108,7 @@ static const struct option longopts[] = {
 	{ "start-grid", required_argument, nullptr, OPT_START_GRID },     // tuning / tests: ntedit_hip_params.start_grid
 	{ "event-budget", required_argument, nullptr, OPT_EVENT_BUDGET }, // tuning / tests: ntedit_hip_params.event_budget
 	{ "shard", required_argument, nullptr, OPT_SHARD },
+	{ "tune", required_argument, nullptr, OPT_TUNE },                 // tuning / tests: ntedit_hip_set_tuning key=value (repeatable)
 	{ "no-map", no_argument, nullptr, OPT_NO_MAP }, // tests: plain FASTA through the streaming reader as well
 	{ "report", no_argument, nullptr, OPT_REPORT },
 	{ "help", no_argument, nullptr, OPT_HELP },
@@ -240,6 +242,7 @@ main(int argc, char** argv)
 	unsigned long long batch_bases = 1ull << 30;
 	unsigned shard_i = 0, shard_n = 1;
 	bool die = false, no_map = false;
+	std::vector<std::pair<std::string, unsigned long long>> tunes;
 	for (int c; (c = getopt_long(argc, argv, shortopts, longopts, nullptr)) != -1;) {
 		switch (c) {
 		case '?':
@@ -337,6 +340,15 @@ main(int argc, char** argv)
 		case OPT_NO_MAP:
 			no_map = true;
 			break;
+		case OPT_TUNE: {
+			const char* eq = strchr(optarg, '=');
+			if (!eq || eq == optarg) {
+				fprintf(stderr, PROGRAM ": invalid option: `--tune %s'\n", optarg);
+				exit(EXIT_FAILURE);
+			}
+			tunes.emplace_back(std::string(optarg, eq - optarg), strtoull(eq + 1, nullptr, 10));
+			break;
+		}
 		case OPT_HELP:
 			fputs(USAGE, stderr);
 			exit(EXIT_SUCCESS);
@@ -379,6 +391,12 @@ main(int argc, char** argv)
 	if (ntedit_hip_create(gpu, &ctx) != 0) {
 		fprintf(stderr, PROGRAM ": error: no usable HIP device %d (this build has no CPU path).\n", gpu);
 		exit(EXIT_FAILURE);
+	}
+	for (const auto& t : tunes) {
+		if (ntedit_hip_set_tuning(ctx, t.first.c_str(), t.second) != 0) {
+			fprintf(stderr, PROGRAM ": error: %s\n", ntedit_hip_last_error(ctx));
+			exit(EXIT_FAILURE);
+		}
 	}
 	// every thread and batch buffer from here on: on the socket the GPU hangs off
 	(void)ntedit_hip_bind_near_device(gpu);

@@ -803,6 +803,84 @@ cover_ends(const Item* arena, size_t arena_items, const uint32_t* ev_first, size
 	return 0;
 }
 
+// Would render_contig accept entry i as a segment whose last halos[i] bases are look-ahead room?  The same
+// predicate, from the node stream alone (no rendering): every applied event ended at or before the cut, the rope was
+// not terminated and ends in the open position node, which starts in front of the cut.  halos[i] == 0: always yes.
+int
+cuts_ok(const Item* arena, size_t arena_items, const uint32_t* ev_first, size_t n_events, uint32_t n_contigs, const uint32_t* lens, const uint32_t* halos,
+        uint8_t* ok)
+{
+	struct St
+	{
+		uint32_t cover = 0;
+		bool terminated = false;
+		int type = 0;
+		uint32_t s_pos = 0, e_pos = 0;
+	};
+	std::vector<St> st(n_contigs);
+	for (uint32_t i = 0; i < n_contigs; i++) {
+		st[i].e_pos = lens[i] ? lens[i] - 1 : 0;
+	}
+	for (size_t ev = 0; ev < n_events; ev++) {
+		const uint32_t fc = ev_first[ev];
+		if (fc == nte::NONE32) {
+			continue;
+		}
+		if ((size_t)fc * nte::CHUNK_ITEMS + 1 >= arena_items) {
+			return -1;
+		}
+		const Item& h = arena[(size_t)fc * nte::CHUNK_ITEMS + 1];
+		if (h.w[0] >= n_contigs) {
+			return -2;
+		}
+		St& c = st[h.w[0]];
+		if (h.w[1] < c.cover) {
+			continue; // overtaken by an earlier event's serial run
+		}
+		c.cover = h.w[2];
+		bool first_node = true, first_chunk = true;
+		uint32_t chunk = fc;
+		while (chunk != nte::NONE32) {
+			if ((size_t)(chunk + 1) * nte::CHUNK_ITEMS > arena_items) {
+				return -1;
+			}
+			const Item* ch = arena + (size_t)chunk * nte::CHUNK_ITEMS;
+			const uint32_t next = ch[0].w[0], cnt = ch[0].w[1];
+			if (cnt > nte::CHUNK_ITEMS) {
+				return -3;
+			}
+			for (uint32_t i = first_chunk ? 2 : 1; i < cnt; i++) {
+				const Item& it = ch[i];
+				if ((it.w[0] & 0xFF) != nte::TAG_NODE || c.terminated) {
+					continue;
+				}
+				const int type = (int)(int8_t)((it.w[0] >> 8) & 0xFF);
+				uint32_t s_pos = it.w[1];
+				if (first_node) {
+					first_node = false;
+					if (type == 0 && s_pos == 0) {
+						s_pos = c.s_pos;
+					}
+				}
+				c.type = type;
+				c.s_pos = s_pos;
+				c.e_pos = it.w[2];
+				if (type == -1) {
+					c.terminated = true;
+				}
+			}
+			first_chunk = false;
+			chunk = next;
+		}
+	}
+	for (uint32_t i = 0; i < n_contigs; i++) {
+		const uint32_t halo = halos[i], len = lens[i];
+		const St& c = st[i];
+		ok[i] = halo == 0 || (halo <= len && !(c.cover > len - halo || c.terminated || c.type != 0 || c.e_pos != len - 1 || c.s_pos >= len - halo));
+	}
+	return 0;
+}
+
 void
 write_vcf_header(FILE* vcf, const char* draft_filename)
 {

@@ -64,6 +64,8 @@ int render_batch(
 
 // per entry: where the serial run of its last applied event ended (0: no applied event)
 int cover_ends(const nte::Item* arena, size_t arena_items, const uint32_t* ev_first, size_t n_events, uint32_t n_contigs, uint32_t* out);
+int cuts_ok(const nte::Item* arena, size_t arena_items, const uint32_t* ev_first, size_t n_events, uint32_t n_contigs, const uint32_t* lens,
+            const uint32_t* halos, uint8_t* ok);
 
 // ntedit.cpp:2192-2211
 void write_vcf_header(FILE* vcf, const char* draft_filename);

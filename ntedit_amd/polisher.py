@@ -113,6 +113,19 @@ class Result:
             raise NtEditHipError("result_cover_ends failed (%d)" % rc)
         return out[:n_contigs]
 
+    def cuts_ok(self, lens, segments):
+        """per entry: will write() accept it with this (pos_offset, halo, flags)?  The renderer's own predicate
+        (ntedit_hip_result_cuts_ok); an entry that fails is polished again joined with its successor."""
+        n = len(lens)
+        seg = self._segment_array(segments, n)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        ok = np.zeros(max(n, 1), dtype=np.uint8)
+        rc = self._lib.ntedit_hip_result_cuts_ok(self._h, n, lens.ctypes.data_as(ctypes.c_void_p),
+                                                 ctypes.cast(seg, ctypes.c_void_p), ok.ctypes.data_as(ctypes.c_void_p))
+        if rc:
+            raise NtEditHipError("result_cuts_ok failed (%d)" % rc)
+        return ok[:n].astype(bool)
+
     def edits(self, blob, offsets, lens, segments=None):
         """(records, pool): every _changes.tsv row as a numpy record (dtype _lib.EDIT_DTYPE) plus the byte pool
         the inserted / deleted bases live in"""
@@ -286,6 +299,10 @@ class Polisher:
         st = res.stats()
         res.free()
         return st
+
+    def set_tuning(self, key, value):
+        """Test / tuning knobs (include/ntedit_hip.h: none of them can change a result)."""
+        self._check(self._lib.ntedit_hip_set_tuning(self._h, key.encode(), int(value)), "set_tuning")
 
     def gather_bench(self, nbytes, n_probes):
         pps, ms = ctypes.c_double(), ctypes.c_float()

@@ -15,7 +15,7 @@ order.  The output is byte-identical to the single-GPU `ntedit` binary's (and to
 What the reference does instead: readAndCorrect's OpenMP loop (ntedit.cpp:2213-2252), contigs handed to threads one
 at a time, output in completion order."""
 import argparse
-import gzip
+import ctypes
 import os
 import sys
 import time
@@ -26,35 +26,31 @@ from . import dist as ndist
 from .polisher import Polisher, default_params, pack_batch
 
 
-def read_fasta_fast(path):
-    """[(header, sequence bytes)] with kseq's record semantics (name + ' ' + comment; sequence = the lines joined,
-    lib/kseq.h:176-215 as used at ntedit.cpp:2223-2230).  Whole-file, C-speed string operations (a 3 GB draft
-    in seconds).  FASTQ input is handled by the `ntedit` binary's reader, not here."""
-    op = gzip.open if path.endswith(".gz") else open
-    with op(path, "rb") as f:
-        data = f.read()
-    recs = []
-    if data.startswith(b">"):
-        pos = 0
-    else:  # (anything in front of the first header line is skipped, like kseq does)
-        i = data.find(b"\n>")
-        pos = i + 1 if i >= 0 else -1
-    n = len(data)
-    while 0 <= pos < n:
-        nxt = data.find(b"\n>", pos)
-        end = n if nxt < 0 else nxt + 1
-        eol = data.find(b"\n", pos, end)
-        if eol < 0:
-            eol = end
-        h = data[pos + 1:eol].rstrip(b"\r")
-        parts = h.split(None, 1)
-        name = parts[0] if parts else b""
-        rest = h[len(name) + 1:] if len(h) > len(name) else b""
-        hdr = name + (b" " + rest if rest else b"")
-        seq = data[eol + 1:end].replace(b"\n", b"").replace(b"\r", b"")
-        recs.append((hdr, seq))
-        pos = end if nxt >= 0 else n
-    return recs
+def read_fasta_fast(path, min_len=0, threads=0):
+    """[(header, sequence bytes)] of the records with >= min_len bases, read by the SAME code the `ntedit` binary
+    ingests with (ntedit_hip_fasta_load: kseq's record semantics, lib/kseq.h:176-215 as used at
+    ntedit.cpp:2223-2230 -- gzip / BGZF told apart by their magic bytes, FASTQ, CR line ends, NUL bytes, text in
+    front of the first header).  Raises on an unreadable, corrupt or truncated file instead of returning a shorter
+    draft."""
+    from . import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    err = ctypes.create_string_buffer(512)
+    rc = lib.ntedit_hip_fasta_load(os.fsencode(path), int(min_len), int(threads), ctypes.byref(h), err, len(err))
+    if rc != 0:
+        raise _lib.NtEditHipError("%s (%d)" % (err.value.decode(errors="replace") or "cannot read the draft", rc))
+    try:
+        nbytes = ctypes.c_uint64()
+        base = lib.ntedit_hip_fasta_blob(h, ctypes.byref(nbytes))
+        recs = []
+        hp, hl, off, ln = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        for i in range(lib.ntedit_hip_fasta_count(h)):
+            lib.ntedit_hip_fasta_record(h, i, ctypes.byref(hp), ctypes.byref(hl), ctypes.byref(off), ctypes.byref(ln))
+            recs.append((ctypes.string_at(hp.value, hl.value) if hl.value else b"",
+                         ctypes.string_at(base + off.value, ln.value) if ln.value else b""))
+        return recs
+    finally:
+        lib.ntedit_hip_fasta_free(h)
 
 
 class HipBackend:
@@ -74,10 +70,12 @@ class HipBackend:
         names = [e[0] for e in entries]
         blob, offs, lens, _ = pack_batch([(e[0], e[1]) for e in entries], 0)
         res = self.pol.polish_batch(blob, offs, lens)
-        cover = res.cover_ends(len(entries))
+        # the renderer's own predicate, asked before anything is written (a refused entry would leave the shard
+        # files half-written): a cut that is not event-free is polished again joined with its successor
+        ok = res.cuts_ok(lens, [e[2] for e in entries])
         segs, bad = [], []
         for i, (_, _, (off, halo, flags)) in enumerate(entries):
-            if halo and int(cover[i]) > int(lens[i]) - halo:
+            if not ok[i]:
                 bad.append(i)
                 flags |= ndist.SEG_SKIP
             segs.append((off, halo, flags))

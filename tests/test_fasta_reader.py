@@ -322,3 +322,54 @@ def test_mapped_reader_bgzf(tmp_path):
         f.write(bgzf_bytes(b"@r1\nACGT\n+\nIIII\n"))
     assert map_dump(p, tmp_path, 4) is None
     assert dump(p, tmp_path) == [(b"r1", b"ACGT")]
+
+
+def _as_driver(recs):
+    """what the reference's caller keeps of kseq's record: contigSeq = seq->seq.s, a C string (ntedit.cpp:2230)"""
+    return [(h, q if q.find(b"\0") < 0 else q[: q.find(b"\0")]) for h, q in recs]
+
+
+def _abi_records(path, **kw):
+    """the C-ABI ingest (ntedit_hip_fasta_load) that python -m ntedit_amd.run reads its draft with"""
+    from ntedit_amd.run import read_fasta_fast
+    return read_fasta_fast(path, **kw)
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_abi_ingest_cases(tmp_path, ci):
+    """the multi-GPU driver must read a draft exactly like the `ntedit` binary does (same readers behind
+    the C ABI): FASTQ records, CR line ends, NUL bytes, text in front of the first header, empty records"""
+    p = str(tmp_path / "in.dat")  # (no .fa / .gz suffix to go by)
+    with open(p, "wb") as f:
+        f.write(CASES[ci])
+    assert _abi_records(p) == _as_driver(model(CASES[ci]))
+    with gzip.open(p + "z", "wb") as f:
+        f.write(CASES[ci])
+    assert _abi_records(p + "z") == _as_driver(model(CASES[ci]))
+    with open(p + "b", "wb") as f:
+        f.write(bgzf_bytes(CASES[ci], block=7))
+    assert _abi_records(p + "b") == _as_driver(model(CASES[ci]))
+
+
+def test_abi_ingest_min_len_fuzz_and_errors(tmp_path):
+    from ntedit_amd import _lib
+    rng = np.random.default_rng(12)
+    alphabet = np.frombuffer(b">@+\n\n\r \tACGTacgtN\0", dtype=np.uint8)
+    p = str(tmp_path / "in")
+    for it in range(200):
+        data = bytes(rng.choice(alphabet, int(rng.integers(0, 160))))
+        with open(p, "wb") as f:
+            f.write(data)
+        z = int(rng.integers(0, 6))
+        assert _abi_records(p, min_len=z) == [r for r in _as_driver(model(data)) if len(r[1]) >= z], data
+    with pytest.raises(_lib.NtEditHipError):
+        _abi_records(str(tmp_path / "missing.fa"))
+    # a truncated gzip stream is an error, not a shorter draft
+    big = b">a\n" + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 300000)) + b"\n>b\nACGT\n"
+    with gzip.open(p + ".gz", "wb") as f:
+        f.write(big)
+    blob = open(p + ".gz", "rb").read()
+    with open(p + ".cut", "wb") as f:
+        f.write(blob[: len(blob) // 2])
+    with pytest.raises(_lib.NtEditHipError):
+        _abi_records(p + ".cut")

@@ -138,13 +138,12 @@ def test_demo_ecoli(tmp_path, oracle_build):
 
 
 @pytest.mark.parametrize("ci", [0, 1, 3, 16, 23, 24, 25, 100, 101])
-def test_binned_screen_matches_oracle(tmp_path, ci, oracle_build, monkeypatch):
-    """the L2-partitioned screening pipeline (write-combining partition of the probes by filter slice: count /
-    scan / scatter, then the L2-resident probe) gives the same bitmap as the oracle, incl. several chunks,
-    non-power-of-two filters, 1..6 hashes (6: falls back to the direct kernel) and a one-slice filter whose ring
-    overflows all the time (the direct-store path).  Cases 100/101: filters of many slices."""
+def test_binned_screen_matches_oracle(tmp_path, ci, oracle_build):
+    """the L2-partitioned screening pipeline (write-combining partition of the probes by filter slice, then the
+    L2-resident probe) gives the same bitmap as the oracle, incl. several chunks, non-power-of-two filters,
+    1..6 hashes (6: falls back to the direct kernel) and a one-slice filter (every record of a workgroup meets
+    the same ring: records wait for their ring slot all the time).  Cases 100/101: filters of many slices."""
     import ntedit_amd
-    monkeypatch.setenv("NTEDIT_HIP_BIN_CHUNK", str(3 * 16384))
     case_kw, _ = H.PARITY_CONFIGS[ci] if ci < 100 else (dict(bfbytes=(1 << 27) if ci == 100 else 100000007 * 8, n=150000,
                                                            flavor="N rep"), {})
     case = H.make_case(str(tmp_path), 4000 + ci, **case_kw)
@@ -153,14 +152,83 @@ def test_binned_screen_matches_oracle(tmp_path, ci, oracle_build, monkeypatch):
     want = H.oracle_screen(blob, bf)
     pol = ntedit_amd.Polisher(0)
     try:
+        pol.set_tuning("bin_chunk", 3 * 16384)
         pol.set_filter(bf["data"], bf["hash_num"], bf["k"])
         pol.set_params(ntedit_amd.default_params(screen_mode=2))
         got = pol.screen(blob)
+        pol.set_tuning("bin_chunk", 0)
+        one_chunk = pol.screen(blob)
         pol.set_params(ntedit_amd.default_params(screen_mode=1))
         direct = pol.screen(blob)
     finally:
         pol.close()
     assert np.array_equal(direct, want)
+    assert np.array_equal(got, want)
+    assert np.array_equal(one_chunk, want)
+
+
+@pytest.mark.parametrize("xcc", [0, 3, 7, 12])
+def test_binned_probe_on_any_xcd_count(tmp_path, xcc, oracle_build):
+    """the probe stage must visit every slice whatever XCDs the device exposes: with every wavefront pretending
+    to run on the same XCD (a device in CPX mode has one; id 12 is one a real device never reports) the bitmap is
+    still the oracle's"""
+    import ntedit_amd
+    case = H.make_case(str(tmp_path), 4700 + xcc, bfbytes=1 << 27, n=120000, flavor="N")
+    bf = H.load_bf(case["bf"])
+    blob, offs, lens, names = H.pack_batch(H.read_fasta(case["draft"]))
+    want = H.oracle_screen(blob, bf)
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.set_filter(bf["data"], bf["hash_num"], bf["k"])
+        pol.set_params(ntedit_amd.default_params(screen_mode=2))
+        pol.set_tuning("force_xcc", xcc + 1)
+        got = pol.screen(blob)
+    finally:
+        pol.close()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("percent", [50, 5])
+def test_binned_overflow_list(tmp_path, percent, oracle_build):
+    """record runs sized far below what the pairs get: the excess goes through the overflow list (direct probes);
+    same bitmap.  A low-complexity draft does this in the field."""
+    import ntedit_amd
+    case = H.make_case(str(tmp_path), 4800 + percent, bfbytes=1 << 26, n=200000, flavor="N rep")
+    bf = H.load_bf(case["bf"])
+    blob, offs, lens, names = H.pack_batch(H.read_fasta(case["draft"]))
+    want = H.oracle_screen(blob, bf)
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.set_filter(bf["data"], bf["hash_num"], bf["k"])
+        pol.set_params(ntedit_amd.default_params(screen_mode=2))
+        pol.set_tuning("bin_cap_percent", percent)
+        got = pol.screen(blob)
+    finally:
+        pol.close()
+    assert np.array_equal(got, want)
+
+
+def test_binned_homopolymer_draft(tmp_path, oracle_build):
+    """a draft of very few distinct k-mers (homopolymer and dinucleotide runs): all probes of a workgroup meet a
+    handful of rings and runs -- ring waits, run overflow -- and the bitmap is still the oracle's"""
+    import ntedit_amd
+    rng = np.random.default_rng(77)
+    parts = [b"A" * 60000, b"AC" * 30000, bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 40000)), b"T" * 50000, b"ACG" * 20000]
+    blob = b"\n".join(parts) + b"\n"
+    truth = str(tmp_path / "t.fa")
+    with open(truth, "w") as fh:
+        for i, s_ in enumerate(parts):
+            fh.write(">c%d\n%s\n" % (i, s_[: len(s_) // 2].decode()))
+    H.mkbf([truth], str(tmp_path / "f.bf"), k=25, hashes=3, nbytes=1 << 26)
+    bf = H.load_bf(str(tmp_path / "f.bf"))
+    want = H.oracle_screen(blob, bf)
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.set_filter(bf["data"], bf["hash_num"], bf["k"])
+        pol.set_params(ntedit_amd.default_params(screen_mode=2))
+        got = pol.screen(blob)
+    finally:
+        pol.close()
     assert np.array_equal(got, want)
 
 
@@ -182,16 +250,16 @@ def test_polish_with_binned_screen(tmp_path, ci, oracle_build):
 
 
 @pytest.mark.parametrize("ci", [0, 1, 9, 10, 20, 22])
-def test_polish_chunk_pipeline(tmp_path, ci, oracle_build, monkeypatch):
+def test_polish_chunk_pipeline(tmp_path, ci, oracle_build):
     """many small pipeline chunks (screening of chunk j+1 overlaps the event machine of chunk j
     on a second stream) must give the same bytes as one chunk"""
-    monkeypatch.setenv("NTEDIT_HIP_CHUNK_BYTES", "50000")
     case_kw, par_kw = H.PARITY_CONFIGS[ci]
     case_kw = dict(case_kw, contigs=7, n=30000)
     case = H.make_case(str(tmp_path), 6000 + ci, **case_kw)
     hp = H.default_params(**par_kw)
     H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), case["rep"])
     pol = _fresh()
+    pol.set_tuning("chunk_bytes", 50000)
     try:
         _load_filters(pol, case)
         pol.set_params(_hip_params(**par_kw))

@@ -123,8 +123,11 @@ def main():
                     cmd[cmd.index("-f") + 1] = case["draft"] + ".bgz"
                 # the L2-partitioned screening pipeline on small inputs, in several record chunks
                 if rng.random() < 0.35:
-                    env["NTEDIT_HIP_SCREEN_MODE"] = "2"
-                    env["NTEDIT_HIP_BIN_CHUNK"] = str(int(rng.choice([16384, 3 * 16384, 1 << 20])))
+                    cmd += ["--tune", "screen_mode=2", "--tune", "bin_chunk=%d" % int(rng.choice([12288, 3 * 12288, 1 << 20]))]
+                    if rng.random() < 0.3:
+                        cmd += ["--tune", "bin_cap_percent=%d" % int(rng.choice([10, 60, 90]))]
+                    if rng.random() < 0.3:
+                        cmd += ["--tune", "force_xcc=%d" % int(rng.integers(1, 17))]
                 if "start_grid" in par_kw:
                     cmd += ["--start-grid", str(par_kw["start_grid"])]
                 if "event_budget" in par_kw:

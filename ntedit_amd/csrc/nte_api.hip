@@ -30,6 +30,7 @@ struct DevBuf
 {
 	void* p = nullptr;
 	size_t cap = 0;
+	bool uncached = false; // allocate as memory the L2 does not keep (hipDeviceMallocUncached)
 };
 
 struct DevFilter
@@ -105,6 +106,8 @@ struct ntedit_hip_ctx
 		u32 inline_tries = ~0u;  // candidates of an indel sweep the deferring launch tries itself (~0: default)
 		u32 screen_lds_pad = 0;  // LDS pad of the direct screening kernel (occupancy experiments)
 		u32 no_rounds = 0, no_early_copy = 0, no_lds_ws = 0;
+		u32 probe_parts_log2 = 0; // the probe stage walks every slice 2^n times, one part of it per walk
+		u32 records_uncached = 0; // the screening records in memory the L2 does not keep (experiments)
 	} tune;
 	DevBuf ev_cover, ev_before, ev_flags, ev_list, ev_bmax; // event rounds
 	u32 cu_count = 256;
@@ -171,7 +174,11 @@ ensure(ntedit_hip_ctx* c, DevBuf& b, size_t bytes)
 		b.cap = 0;
 	}
 	size_t want = bytes + bytes / 8 + 256;
-	HIP_TRY(c, hipMalloc(&b.p, want));
+	if (b.uncached) {
+		HIP_TRY(c, hipExtMallocWithFlags(&b.p, want, hipDeviceMallocUncached));
+	} else {
+		HIP_TRY(c, hipMalloc(&b.p, want));
+	}
 	b.cap = want;
 	return 0;
 }
@@ -382,16 +389,18 @@ bool
 binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_log2, u32* n_slices)
 {
 	u32 mode = c->tune.screen_mode ? c->tune.screen_mode : c->hp.screen_mode;
-	if (mode == 1 || c->bin_fallback || f.hash_num == 0 || f.hash_num > 5 || f.counting || c->hp.snv) {
+	// (-s 1 has no screening probes at all: k_screen only marks the k-mers of accepted bases)
+	if (mode == 1 || c->bin_fallback || f.hash_num == 0 || f.hash_num > 5 || c->hp.snv) {
 		return false;
 	}
-	u32 slog = 24; // 2 MiB slices while the filter has at most WC_MAX_SLICES of them, 4 / 8 MiB beyond
+	// slices of 2 MiB of filter (2^24 bit slots, 2^21 counters) while it has at most WC_MAX_SLICES of them, 4 / 8 MiB beyond
+	u32 slog = f.counting ? 21 : 24;
 	u64 ns = (f.bits + (1ULL << slog) - 1) >> slog;
 	while (ns > (u64)WC_MAX_SLICES) {
 		slog++;
 		ns = (f.bits + (1ULL << slog) - 1) >> slog;
 	}
-	if (slog > 26 || n >= (1ULL << (63 - slog)) || wc_lds_bytes(c->dp.k) + 1024 > c->lds_per_block) {
+	if (slog > (f.counting ? 23u : 26u) || n >= (1ULL << (63 - slog)) || wc_lds_bytes(c->dp.k) + 1024 > c->lds_per_block) {
 		return false; // slices beyond 8 MiB do not stay in an XCD's 4 MiB L2 long enough to matter
 	}
 	*slice_log2 = slog;
@@ -399,7 +408,7 @@ binned_applicable(const ntedit_hip_ctx* c, const Filter& f, u64 n, u32* slice_lo
 	if (mode == 2) {
 		return true;
 	}
-	return f.bits >= (1ULL << 30) && n >= (1ULL << 26); // auto: filters >= 128 MiB, batches >= 64 Mbases
+	return f.bits >= (f.counting ? 1ULL << 27 : 1ULL << 30) && n >= (1ULL << 26); // auto: filters >= 128 MiB, batches >= 64 Mbases
 }
 
 // The binned screening of this context lost probe records (an overflow list overflowed: a draft made of very few
@@ -532,7 +541,8 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 	}
 	const WcPlan plan0 = plan_wc(c, span < chunk ? span : chunk, f.hash_num, n_slices);
 	const u32 ovf_cap = 1u << 22; // 64 MiB of overflow entries per chunk; beyond that the direct kernel takes over
-	const size_t ctl_words = CTL_WORK + (size_t)n_slices + 1;
+	const u32 parts_log2 = c->tune.probe_parts_log2;
+	const size_t ctl_words = CTL_WORK + ((size_t)n_slices << parts_log2) + 1;
 	int rc;
 	if (!c->bin_lost.p) {
 		if ((rc = ensure(c, c->bin_lost, 4))) {
@@ -542,12 +552,12 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 	}
 	if ((rc = ensure(c, c->bin_records, plan0.record_bytes)) ||
 	    (rc = ensure(c, c->bin_fill, (size_t)n_slices * plan0.n_wg * 4)) ||
-	    (rc = ensure(c, c->bin_ctl, (ctl_words + 1) * 4)) ||
+	    (rc = ensure(c, c->bin_ctl, (ctl_words + 8) * 4)) ||
 	    (rc = ensure(c, c->bin_ovf, (size_t)ovf_cap * sizeof(WcOvf)))) {
 		return rc;
 	}
 	u32* d_ctl = (u32*)c->bin_ctl.p;
-	u32* d_ovf_count = d_ctl + ctl_words;
+	u32* d_ovf_count = d_ctl + ctl_words; // (+ 3 words of NTE_WC_STATS counters)
 	{
 		// the probe stage ORs into the bitmap: clear the words of the range first
 		const u64 w0 = pos_begin / 64, w1 = (pos_end + 63) / 64 < n_words ? (pos_end + 63) / 64 : n_words;
@@ -590,7 +600,7 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 			}
 			HIP_TRY(c, hipStreamWaitEvent(stream, c->h2d_ev[piece], 0));
 		}
-		HIP_TRY(c, hipMemsetAsync(d_ctl, 0, (ctl_words + 1) * 4, stream));
+		HIP_TRY(c, hipMemsetAsync(d_ctl, 0, (ctl_words + 8) * 4, stream));
 		HIP_TRY(c, hipEventRecord(tev[0], stream));
 		if ((rc = run_wc_partition(c, stream, w))) {
 			return rc;
@@ -600,16 +610,19 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		pa.filter = f.data;
 		pa.records = (const u64*)c->bin_records.p;
 		pa.fill = (const u32*)c->bin_fill.p;
-		pa.n_slices = n_slices;
+		pa.n_slices = n_slices << parts_log2;
 		pa.slog = slog;
+		pa.parts_log2 = parts_log2;
 		pa.n_wg = plan.n_wg;
 		pa.cap = plan.cap;
 		pa.ctl = d_ctl;
 		pa.absent32 = (u32*)d_bitmap;
 		pa.force_xcc = c->tune.force_xcc ? c->tune.force_xcc - 1 : PROBE_XCC_ANY;
-		hipLaunchKernelGGL(k_bin_probe, dim3(c->cu_count * 8), dim3(PROBE_TPB), 0, stream, pa);
+		pa.counting = f.counting;
+		pa.count_lo = c->dp.min_thr > 1 ? c->dp.min_thr : 1;
+		hipLaunchKernelGGL(k_bin_probe, dim3(c->cu_count * (2048 / PROBE_TPB)), dim3(PROBE_TPB), 0, stream, pa);
 		hipLaunchKernelGGL(k_ovf_probe, dim3(64), dim3(256), 0, stream, f.data, (const WcOvf*)c->bin_ovf.p, (const u32*)d_ovf_count, ovf_cap, slog,
-		                   (u32*)d_bitmap);
+		                   (u32*)d_bitmap, (u32)f.counting, pa.count_lo);
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipEventRecord(tev[2], stream));
 		// overflow entries that did not fit are lost probes: the caller must look at this before it trusts the bitmap
@@ -621,6 +634,12 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 			(void)hipEventElapsedTime(&t_probe, tev[1], tev[2]);
 			u32 ovf_n = 0;
 			(void)hipMemcpy(&ovf_n, d_ovf_count, 4, hipMemcpyDeviceToHost);
+#ifdef NTE_WC_STATS
+			u32 stats[4] = { 0, 0, 0, 0 };
+			(void)hipMemcpy(stats, d_ovf_count + 1, 16, hipMemcpyDeviceToHost);
+			fprintf(stderr, "[ntedit_hip] scatter: %u wavefront rounds, %u extra passes, %u lanes with a record that found its ring half taken, %u deferred group flushes that had to wait again\n",
+			        stats[1], stats[0], stats[2], stats[3]);
+#endif
 			fprintf(stderr, "[ntedit_hip] binned chunk %llu k-mers, %u slices of 2^%u bits, %u x %u-record runs per slice (%.2f GB), %u overflow records: partition %.3f ms, probe %.3f ms\n",
 			        (unsigned long long)(end - begin), n_slices, slog, plan.n_wg, plan.cap, plan.record_bytes / 1e9, ovf_n, t_part, t_probe);
 		}
@@ -1419,10 +1438,21 @@ PolishRun::launch_screening(int attempt)
 		if (h2d_overlap && attempt == 0) {
 			HIP_TRY(c, hipMemcpyAsync(c->seq.p, bases, n, hipMemcpyHostToDevice, sA));
 		}
+		u32 slog = 0, nsl = 0;
+		const bool bin_chunks = binned_applicable(c, f0, n, &slog, &nsl);
+		if (!bin_chunks) {
+			c->bin_chunks_last = 0;
+		}
 		for (size_t j = 0; j < n_ch; j++) {
 			HIP_TRY(c, hipEventRecord(c->chunk_ev[2 * j], sA));
-			if ((rc = launch_screen_tiles<false>(
-			         c, sA, d_seq, n, f0, d_bitmap, n_words, chunks[j].t0, chunks[j].t1 - chunks[j].t0, screen_pad))) {
+			if (bin_chunks) {
+				// (the probe stage of chunk j+1 leaves room on the CUs for the event machine of chunk j)
+				const u64 p0 = chunks[j].t0 * SCREEN_TILE, p1 = chunks[j].t1 * SCREEN_TILE;
+				if (p1 > p0 && (rc = run_screen_binned(c, d_seq, n, f0, d_bitmap, n_words, slog, nsl, sA, p0, p1 < n ? p1 : n))) {
+					return rc;
+				}
+			} else if ((rc = launch_screen_tiles<false>(
+			                c, sA, d_seq, n, f0, d_bitmap, n_words, chunks[j].t0, chunks[j].t1 - chunks[j].t0, screen_pad))) {
 				return rc;
 			}
 			HIP_TRY(c, hipEventRecord(c->chunk_ev[2 * j + 1], sA));
@@ -1582,8 +1612,8 @@ PolishRun::run_chunk_events(size_t j)
 
 	// ---- rounds (see "event rounds" in nte_kernels.hip): primaries, then the secondaries their
 	// primary's run does not overtake, then -- practically never -- whatever a verification rejects.
-	// Pipeline chunks and SNV mode run everything in one round.
-	const bool rounds = n_ch == 1 && !c->dp.snv && n_ev < 0xFFFFFF00ull && !c->tune.no_rounds;
+	// SNV mode runs everything in one round.
+	const bool rounds = !c->dp.snv && n_ev < 0xFFFFFF00ull && !c->tune.no_rounds;
 	u32* d_list = nullptr;
 	u64* d_before = nullptr;
 	u64* d_bmax = nullptr;
@@ -2388,6 +2418,14 @@ ntedit_hip_set_tuning(ntedit_hip_ctx* c, const char* key, uint64_t value)
 		t.no_early_copy = (u32)value;
 	} else if (k == "no_lds_ws") {
 		t.no_lds_ws = (u32)value;
+	} else if (k == "probe_parts_log2") {
+		t.probe_parts_log2 = (u32)value < 4 ? (u32)value : 3;
+	} else if (k == "records_uncached") {
+		t.records_uncached = (u32)value;
+		if (c->bin_records.uncached != (value != 0)) {
+			release(c->bin_records);
+			c->bin_records.uncached = value != 0;
+		}
 	} else if (k == "bin_fallback") {
 		c->bin_fallback = value != 0;
 	} else {

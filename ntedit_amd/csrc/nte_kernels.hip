@@ -265,23 +265,29 @@ struct BinArgs
 	u64* records;    // runs of `cap` records, one per (slice, partition workgroup) pair
 };
 
-// Probe stage.  A slice's 2-4 MiB of filter fit the 4 MiB L2 of ONE XCD, so all wavefronts of an XCD work on the
-// same slice at the same time: a wavefront asks the hardware which XCD it runs on (HW_REG_XCC_ID) and pulls
-// 512-record pieces of that XCD's CURRENT slice from the slice's piece counter.  Slices are not tied to XCDs: the
-// wavefront that draws the first piece index past the end of a slice takes the next unclaimed slice from a global
-// counter and publishes it as its XCD's current one.  Every slice is therefore probed completely whatever the number
-// of XCDs the device exposes (compute partitioning: 1, 2, 4 or 8), whichever of them receive workgroups, and
+// Probe stage.  A slice's 2-4 MiB of filter fit the 4 MiB L2 of ONE XCD, so all workgroups of an XCD work on the
+// same slice at the same time: a workgroup asks the hardware which XCD it runs on (HW_REG_XCC_ID) and draws
+// stretches of that XCD's CURRENT slice from the slice's counter, one 512-record step per wavefront.  Large
+// workgroups (16 wavefronts, two per CU) keep the draws rare (a counter that everybody on an XCD draws from serves
+// ~15 M draws/s) AND the work in flight small: when the XCD moves on to its next slice only 64 stretches of the old one
+// are still being probed (two slices do not fit the L2 together; with a draw per wavefront half a slice was in flight
+// at every switch and a quarter of all probes missed the L2).
+// Slices are not tied to XCDs: the workgroup whose draw reaches the end of a slice takes the next unclaimed slice from a
+// global counter and publishes it as its XCD's current one.  Every slice is therefore probed completely whatever the
+// number of XCDs the device exposes (compute partitioning: 1, 2, 4 or 8), whichever of them receive workgroups, and
 // however fast each one is; placement only affects speed, never the result.
 // ctl[] (zeroed before the launch): [0] next unclaimed slice, [1..16] current slice of XCD x (0 = none yet,
-// 1 = being claimed, s + 2 = slice s), [32 + s] piece counter of slice s.
-constexpr int PROBE_TPB = 256;
+// 1 = being claimed, s + 2 = slice s), [32 + s] records of slice s handed out so far.
+// A slice's records: n_wg runs of `cap` records; in the counter's coordinates every run takes capr = cap rounded up to
+// whole steps, so no step crosses runs.
+#ifndef NTE_PROBE_TPB
+#define NTE_PROBE_TPB 1024
+#endif
+constexpr int PROBE_TPB = NTE_PROBE_TPB;
+constexpr int PROBE_WAVES = PROBE_TPB / 64;
 constexpr int PROBE_PER = 8;                  // records per lane and step, all in flight together
 constexpr int PROBE_STEP = 64 * PROBE_PER;    // records per step of a wavefront
-#ifndef NTE_PROBE_STEPS
-#define NTE_PROBE_STEPS 8
-#endif
-constexpr int PROBE_PIECE = PROBE_STEP * NTE_PROBE_STEPS; // records per piece: one draw from the slice's counter (a counter
-                                                          // that every wavefront of an XCD draws from serves ~15 M draws/s)
+constexpr u32 PROBE_DRAW = PROBE_STEP * PROBE_WAVES; // records per draw of a workgroup
 constexpr u32 CTL_NEXT = 0, CTL_CUR = 1, CTL_WORK = 32;
 constexpr u32 PROBE_XCC_ANY = 0xFFFFFFFFu;
 
@@ -296,7 +302,11 @@ struct ProbeArgs
 	u32 cap;
 	u32* ctl;
 	u32* absent32;
-	u32 force_xcc;   // PROBE_XCC_ANY, or the XCD id every wavefront pretends to run on (tests)
+	u32 force_xcc;   // PROBE_XCC_ANY, or the XCD id every workgroup pretends to run on (tests)
+	u32 counting;    // the filter holds 8-bit counters: a slot is a byte, "absent" = counter < count_lo
+	u32 count_lo;    // max(1, -p) (ntedit.cpp:1806)
+	u32 parts_log2;  // a slice is walked 2^parts_log2 times, each walk probing the records of one part of it: the part
+	                 // (not the whole slice) has to stay in the XCD's L2 next to the record stream; n_slices counts walks
 };
 
 __device__ __forceinline__ u32
@@ -312,24 +322,23 @@ ctl_load(const u32* p)
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One lane: the next piece of the XCD's current slice, moving on to further slices as they run out.  `p` is a piece
-// index already drawn from slice `sl` (or sl == NONE32: nothing drawn yet).  Returns false when no slice is left.
+// One thread: the next stretch [p, p + PROBE_DRAW) of the XCD's current slice, moving on to further slices as they run
+// out.  On entry {sl, p} is a draw already made from slice `sl` (or sl == NONE32: none yet).  Returns false when no
+// slice is left.
 __device__ __forceinline__ bool
 probe_claim(u32* __restrict__ ctl, u32 xcd, u32 n_slices, u32 total, u32& sl, u32& p)
 {
 	u32* cur = ctl + CTL_CUR + xcd;
 	for (;;) {
-		if (sl != NONE32) {
-			if (p < total) {
-				return true;
-			}
-			if (p == total) {
-				// this draw closed the slice: open the next one for the whole XCD
+		if (sl != NONE32 && p < total) {
+			if (total - p <= PROBE_DRAW) {
+				// this draw reaches the end of the slice: open the next one for the whole XCD
 				const u32 nx = atomicAdd(&ctl[CTL_NEXT], 1u);
 				__hip_atomic_store(cur, nx + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
+			return true;
 		}
-		// the XCD's current slice (another wavefront may be switching it right now)
+		// the XCD's current slice (another workgroup may be switching it right now)
 		u32 v = ctl_load(cur);
 		for (;;) {
 			if (v == 0) {
@@ -348,69 +357,80 @@ probe_claim(u32* __restrict__ ctl, u32 xcd, u32 n_slices, u32 total, u32& sl, u3
 		if (sl >= n_slices) {
 			return false;
 		}
-		p = atomicAdd(&ctl[CTL_WORK + sl], 1u);
+		p = atomicAdd(&ctl[CTL_WORK + sl], PROBE_DRAW);
 	}
 }
 
 __global__ __launch_bounds__(PROBE_TPB) void
 k_bin_probe(ProbeArgs a)
 {
-	const u32 lane = threadIdx.x & 63;
+	__shared__ u32 s_draw[2][4]; // {ok, slice, start}, double-buffered: one barrier per draw
+	const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const u64 off_mask = (1ULL << a.slog) - 1;
 	const u32 xcd = a.force_xcc == PROBE_XCC_ANY ? xcc_id() : (a.force_xcc & 15u);
-	const u32 ppr = (a.cap + PROBE_PIECE - 1) / PROBE_PIECE; // pieces per run
-	const u32 total = a.n_wg * ppr;
-	u32 sl = NONE32, p = 0;
-	for (;;) {
-		{
-			u32 ok = 0;
-			if (lane == 0) {
-				ok = probe_claim(a.ctl, xcd, a.n_slices, total, sl, p) ? 1u : 0u;
-			}
-			ok = __builtin_amdgcn_readfirstlane(ok);
-			sl = __builtin_amdgcn_readfirstlane(sl);
-			p = __builtin_amdgcn_readfirstlane(p);
-			if (!ok) {
-				return;
-			}
-		}
-		// draw the piece after this one now: its round trip hides behind the probes
-		u32 pn = 0;
-		if (lane == 0) {
-			pn = atomicAdd(&a.ctl[CTL_WORK + sl], 1u);
-		}
-		const u32 w = p / ppr;
-		const u32 i0 = (p - w * ppr) * PROBE_PIECE;
-		const u32 fill = a.fill[(size_t)sl * a.n_wg + w];
-		if (i0 < fill) {
-			const u32 n = fill - i0 < (u32)PROBE_PIECE ? fill - i0 : (u32)PROBE_PIECE;
-			const u64* __restrict__ src = a.records + ((u64)(sl * a.n_wg + w) * a.cap + i0);
-			const u8* __restrict__ fs = a.filter + ((u64)sl << (a.slog - 3));
-			for (u32 s0 = 0; s0 < n; s0 += PROBE_STEP) {
-				u64 rec[PROBE_PER];
-				u8 byte[PROBE_PER];
-#pragma unroll
-				for (int q = 0; q < PROBE_PER; q++) {
-					const u32 i = s0 + (u32)q * 64 + lane;
-					// (non-temporal: the records are read once; the slice they probe should keep the XCD's L2)
-					rec[q] = i < n ? __builtin_nontemporal_load(src + i) : WC_EMPTY_REC;
-				}
-#pragma unroll
-				for (int q = 0; q < PROBE_PER; q++) {
-					const u32 off = (u32)(rec[q] & off_mask);
-					byte[q] = rec[q] != WC_EMPTY_REC ? fs[off >> 3] : (u8)0xFF;
-				}
-#pragma unroll
-				for (int q = 0; q < PROBE_PER; q++) {
-					const u32 off = (u32)(rec[q] & off_mask);
-					if (!((byte[q] >> (off & 7)) & 1)) {
-						const u64 pos = (rec[q] & WC_REC_POS_MASK) >> a.slog;
-						atomicOr(&a.absent32[pos >> 5], 1u << (pos & 31));
-					}
-				}
+	const u32 capr = (a.cap + PROBE_STEP - 1) / PROBE_STEP * PROBE_STEP; // a run in the counter's coordinates
+	const u32 total = a.n_wg * capr;
+	const u32 part_shift = a.slog - a.parts_log2;
+	const u32 bsh = a.counting ? 0u : 3u; // slots per byte, as a shift
+	u32 sl = NONE32, p = 0; // (thread 0: the draw made ahead)
+	for (u32 it = 0;; it++) {
+		u32* d = s_draw[it & 1];
+		if (threadIdx.x == 0) {
+			const bool ok = probe_claim(a.ctl, xcd, a.n_slices, total, sl, p);
+			d[0] = ok ? 1u : 0u;
+			d[1] = sl;
+			d[2] = p;
+			if (ok) {
+				// draw the stretch after this one now: its round trip hides behind the probes
+				p = atomicAdd(&a.ctl[CTL_WORK + sl], PROBE_DRAW);
 			}
 		}
-		p = pn;
+		__syncthreads();
+		if (!d[0]) {
+			return;
+		}
+		const u32 dsl = d[1];
+		const u32 at = d[2] + wave * PROBE_STEP;
+		if (at >= total) {
+			continue;
+		}
+		const u32 rsl = dsl >> a.parts_log2;                 // the slice of the record array
+		const u32 part = dsl & ((1u << a.parts_log2) - 1);  // the part of it this walk probes
+		const u8* __restrict__ fs = a.filter + ((u64)rsl << (a.slog - bsh));
+		const u32 w = at / capr;
+		const u32 i0 = at - w * capr;
+		const u32 fill = a.fill[(size_t)rsl * a.n_wg + w];
+		if (i0 >= fill) {
+			continue;
+		}
+		const u32 n = fill - i0 < (u32)PROBE_STEP ? fill - i0 : (u32)PROBE_STEP;
+		const u64* __restrict__ src = a.records + ((u64)(rsl * a.n_wg + w) * a.cap + i0);
+		u64 rec[PROBE_PER];
+		u8 byte[PROBE_PER];
+#pragma unroll
+		for (int q = 0; q < PROBE_PER; q++) {
+			const u32 i = (u32)q * 64 + lane;
+			// (non-temporal: the records are read once; the slice they probe should keep the XCD's L2)
+			rec[q] = i < n ? __builtin_nontemporal_load(src + i) : WC_EMPTY_REC;
+		}
+#pragma unroll
+		for (int q = 0; q < PROBE_PER; q++) {
+			const u32 off = (u32)(rec[q] & off_mask);
+			if (rec[q] == WC_EMPTY_REC || (off >> part_shift) != part) {
+				rec[q] = WC_EMPTY_REC; // (padding, or another walk's record)
+			}
+			byte[q] = rec[q] != WC_EMPTY_REC ? fs[off >> bsh] : (u8)0xFF;
+		}
+#pragma unroll
+		for (int q = 0; q < PROBE_PER; q++) {
+			const u32 off = (u32)(rec[q] & off_mask);
+			// plain filter: the bit; counting filter: the counter must reach max(1, -p)
+			const bool absent = a.counting ? (u32)byte[q] < a.count_lo : !((byte[q] >> (off & 7)) & 1);
+			if (absent && rec[q] != WC_EMPTY_REC) {
+				const u64 pos = (rec[q] & WC_REC_POS_MASK) >> a.slog;
+				atomicOr(&a.absent32[pos >> 5], 1u << (pos & 31));
+			}
+		}
 	}
 }
 

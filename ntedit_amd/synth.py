@@ -144,3 +144,30 @@ class SyntheticJob:
     @property
     def n_bytes(self):
         return self.batch.numel()
+
+
+def counting_filter_from_plain(polisher, k, hash_num, device="cuda", seed=7):
+    """Turns the PLAIN primary filter the polisher holds (n bytes = 8n bit slots) into a counting filter of 8n
+    8-bit counters in HBM and makes it the polisher's primary filter: a k-mer's counting slots hv % (8n) are its bit
+    slots, so every truth k-mer gets non-zero counters.  Counter values are 1..4, a fixed function of the slot
+    index, so that -p 2 / -q cut into the present k-mers.  (Synthetic content for throughput / parity runs: the
+    conservative-update insertion of btllib's KmerCountingBloomFilter8 is sequential and stays on the host,
+    oracle/mkbf.c.)  Returns the counter tensor; the caller keeps it alive while the polisher uses it."""
+    dev = torch.device(device)
+    bits = torch.from_numpy(polisher.filter_download(0)).to(dev)
+    n = bits.numel()
+    counters = torch.empty(n * 8, dtype=torch.uint8, device=dev)
+    view = counters.view(n, 8)
+    step = 1 << 24
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        b = bits[lo:hi].to(torch.int32)
+        idx = torch.arange(lo * 8, hi * 8, device=dev, dtype=torch.int64).view(-1, 8)
+        val = (1 + ((idx * 2654435761 + seed) >> 13) % 4).to(torch.uint8)
+        for j in range(8):
+            view[lo:hi, j] = torch.where(((b >> j) & 1) != 0, val[:, j], torch.zeros_like(val[:, j]))
+        del b, idx, val
+    del bits
+    torch.cuda.synchronize(dev)
+    polisher.set_filter_device(counters.data_ptr(), counters.numel(), hash_num, k, counting=True)
+    return counters

@@ -2569,6 +2569,16 @@ mt_run(mt_job* j, unsigned n_threads)
 	pthread_mutex_destroy(&j->mu);
 }
 
+/* the in-memory primary filter of the ora_*_flat* entry points is a KmerCountingBloomFilter8 (ntedit.cpp:357-361):
+ * set before the call, process-wide (test infrastructure) */
+static int flat_primary_counting = 0;
+
+void
+ora_set_flat_counting(int counting)
+{
+	flat_primary_counting = counting;
+}
+
 static void
 flat_bf(ora_bf* bf, const uint8_t* data, uint64_t bytes, unsigned hash_num, unsigned k)
 {
@@ -2644,6 +2654,7 @@ ora_polish_batch_flat_mt_files(
 {
 	ora_bf bf, rep;
 	flat_bf(&bf, bf_data, bf_bytes, hash_num, k);
+	bf.counting = flat_primary_counting;
 	flat_bf(&rep, rep_data, rep_bytes, rep_hash_num, k);
 	ora_params p = *params;
 	p.secbf = rep_data != NULL;

@@ -198,6 +198,8 @@ uint64_t ora_polish_batch_flat_mt(
  * body rows (no VCF header, no annotations) are buffered and written in INPUT order after the threads
  * are done = the files of the reference at -t 1.  Contigs are handed out longest first.  Paths may be
  * NULL; rep_data may be NULL.  Used by the full-size parity tests (every contig of a 3 Gbp batch). */
+/* the primary in-memory filter of the next ora_polish_batch_flat_mt_files() calls is a counting filter (0 / 1) */
+void ora_set_flat_counting(int counting);
 uint64_t ora_polish_batch_flat_mt_files(
     const char* bases,
     const uint64_t* offsets,

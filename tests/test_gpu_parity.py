@@ -2,6 +2,7 @@
 
 Bit-exact bar: bitmaps, filter bytes, _edited.fa and _changes.tsv must be
 byte-identical.  Nothing here reads /root/reference."""
+import ctypes
 import filecmp
 import os
 
@@ -249,8 +250,9 @@ def test_polish_with_binned_screen(tmp_path, ci, oracle_build):
     assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "g_edited.fa"), shallow=False)
 
 
+@pytest.mark.parametrize("screen_mode", [0, 2])
 @pytest.mark.parametrize("ci", [0, 1, 9, 10, 20, 22])
-def test_polish_chunk_pipeline(tmp_path, ci, oracle_build):
+def test_polish_chunk_pipeline(tmp_path, ci, screen_mode, oracle_build):
     """many small pipeline chunks (screening of chunk j+1 overlaps the event machine of chunk j
     on a second stream) must give the same bytes as one chunk"""
     case_kw, par_kw = H.PARITY_CONFIGS[ci]
@@ -262,7 +264,7 @@ def test_polish_chunk_pipeline(tmp_path, ci, oracle_build):
     pol.set_tuning("chunk_bytes", 50000)
     try:
         _load_filters(pol, case)
-        pol.set_params(_hip_params(**par_kw))
+        pol.set_params(_hip_params(screen_mode=screen_mode, **par_kw))
         st = pol.polish_records(H.read_fasta(case["draft"]), str(tmp_path / "g"))
         assert st.screen_launches >= 4
         # and again on the warm context (buffers already sized)
@@ -364,7 +366,7 @@ def _differing_contigs(fa_a, fa_b, tsv_a, tsv_b, limit=5):
     return n_bad, bad
 
 
-def _compare_every_contig(pol, job, tmp_path, tag, capsys, rep=False, **kw):
+def _compare_every_contig(pol, job, tmp_path, tag, capsys, rep=False, counting=False, **kw):
     """Polish the whole HBM-resident batch on the GPU, render ALL of it, run the multi-threaded oracle on ALL
     of it with the same filter(s) (downloaded from HBM), and compare the complete _edited.fa, _changes.tsv and
     VCF body byte for byte: every contig of the batch, 0 differences allowed.  Returns the GPU stats."""
@@ -387,8 +389,12 @@ def _compare_every_contig(pol, job, tmp_path, tag, capsys, rep=False, **kw):
     ofa, otsv, ovcf = (str(tmp_path / (tag + s)) for s in ("_ora_edited.fa", "_ora_changes.tsv", "_ora_body.vcf"))
     threads = H.usable_cpus()
     t0 = time.time()
-    done = H.oracle_polish_flat_mt_files(host, job.offsets, job.lens, names, bits, h, k, threads, fa_path=ofa,
-                                         tsv_path=otsv, vcf_path=ovcf, rep_bits=rbits, rep_hash_num=h, **kw)
+    H.oracle_lib().ora_set_flat_counting(ctypes.c_int(1 if counting else 0))
+    try:
+        done = H.oracle_polish_flat_mt_files(host, job.offsets, job.lens, names, bits, h, k, threads, fa_path=ofa,
+                                             tsv_path=otsv, vcf_path=ovcf, rep_bits=rbits, rep_hash_num=h, **kw)
+    finally:
+        H.oracle_lib().ora_set_flat_counting(ctypes.c_int(0))
     t_ora = time.time() - t0
     assert done == job.n_bases
     same = (filecmp.cmp(fa, ofa, shallow=False), filecmp.cmp(tsv, otsv, shallow=False),
@@ -481,6 +487,46 @@ def test_config2_250mbp_every_contig(tmp_path, oracle_build, capsys):
         st, host, names = _compare_every_contig(pol, job, tmp_path, "configs2", capsys)
         assert 0.8e-3 * job.n_bases < st.substitutions < 1.2e-3 * job.n_bases
         assert st.insertions > 0 and st.deletions > 0
+    finally:
+        pol.close()
+
+
+def test_snv_mode_250mbp_every_contig(tmp_path, oracle_build, capsys):
+    """SURVEY 8f-2 at size: -s 1 on a 250 Mbp draft (2,500 x 100 kbp, 512 MiB filter): every position of every
+    contig is re-assessed (no screen gate), _edited.fa / _changes.tsv / VCF body byte-identical to the oracle
+    (ntedit.cpp:1806,1865,1890-1914)."""
+    import ntedit_amd
+    from ntedit_amd.synth import SyntheticJob
+
+    total = float(os.environ.get("NTEDIT_SNV_BASES", "250e6"))
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.set_params(ntedit_amd.default_params(snv=1, max_insertions=0, max_deletions=0))
+        job = SyntheticJob(pol, total, k=25, hash_num=3, filter_bytes=1 << 29, contig_len=100_000, n_runs=False)
+        st, host, names = _compare_every_contig(pol, job, tmp_path, "snv250", capsys, snv=1, max_insertions=0, max_deletions=0)
+        assert st.substitutions > 0.5e-3 * job.n_bases
+    finally:
+        pol.close()
+
+
+def test_counting_filter_250mbp_every_contig(tmp_path, oracle_build, capsys):
+    """SURVEY 8f-1 at size: a 4 GiB counting filter (2^32 8-bit counters, synthetic contents: every truth k-mer has
+    counters 1..4), -p 2 (k-mers seen once count as absent), 250 Mbp draft: the binned screening on counters and the
+    event machine's median coverage, every contig byte-identical to the oracle (ntedit.cpp:357-361,373-376,455-463,1806)."""
+    import ntedit_amd
+    from ntedit_amd.synth import SyntheticJob, counting_filter_from_plain
+
+    total = float(os.environ.get("NTEDIT_CBF_BASES", "250e6"))
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.set_params(ntedit_amd.default_params())
+        job = SyntheticJob(pol, total, k=25, hash_num=3, filter_bytes=1 << 29, contig_len=100_000, n_runs=False)
+        counters = counting_filter_from_plain(pol, 25, 3)
+        pol.set_params(ntedit_amd.default_params(min_threshold=2))
+        st, host, names = _compare_every_contig(pol, job, tmp_path, "cbf250", capsys, counting=True, min_threshold=2)
+        assert st.screen_binned
+        assert st.substitutions > 0.5e-3 * job.n_bases
+        del counters
     finally:
         pol.close()
 

@@ -26,6 +26,8 @@ CASES = [
     ("overflow_50", dict(bfbytes=1 << 26, n=200000, flavor="N rep"), {"bin_cap_percent": 50}),
     ("overflow_5", dict(bfbytes=1 << 26, n=200000, flavor="N rep"), {"bin_cap_percent": 5}),
     ("big_3M", dict(bfbytes=1 << 28, n=1000000, contigs=3), {}),
+    ("counting_p1", dict(bfbytes=1 << 20, n=40000, flavor="cbf"), {}),
+    ("counting_p2", dict(bfbytes=1 << 21, n=40000, flavor="cbf N"), {"min_threshold": 2}),
 ]
 
 
@@ -34,14 +36,16 @@ def child(idx):
     import helpers as H
     import ntedit_amd
     name, kw, tune = CASES[idx]
+    tune = dict(tune)
     tmp = tempfile.mkdtemp(prefix="screen_check_")
     case = H.make_case(tmp, 9100 + idx, **kw)
     bf = H.load_bf(case["bf"])
     blob, offs, lens, names = H.pack_batch(H.read_fasta(case["draft"]))
-    want = H.oracle_screen(blob, bf)
+    min_thr = tune.pop("min_threshold", 1) if isinstance(tune, dict) else 1
+    want = H.oracle_screen(blob, bf, min_threshold=min_thr)
     pol = ntedit_amd.Polisher(0)
-    pol.set_filter(bf["data"], bf["hash_num"], bf["k"])
-    pol.set_params(ntedit_amd.default_params(screen_mode=2))
+    pol.set_filter(bf["data"], bf["hash_num"], bf["k"], counting=bool(bf.get("counting")))
+    pol.set_params(ntedit_amd.default_params(screen_mode=2, min_threshold=min_thr))
     pol.set_tuning("bin_timing", 1)
     for k_, v in tune.items():
         pol.set_tuning(k_, v)

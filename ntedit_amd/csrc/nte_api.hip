@@ -911,6 +911,7 @@ ntedit_hip_load_filter_file(ntedit_hip_ctx* c, int slot, const char* path)
 	void* bounce = nullptr;
 	if (hipHostMalloc(&bounce, CH, hipHostMallocDefault) != hipSuccess) {
 		fclose(f);
+		(void)drop_filter(c, slot);
 		return fail(c, NTEDIT_E_DEVICE, "hipHostMalloc failed");
 	}
 	u64 done = 0;

@@ -281,7 +281,7 @@ struct BinArgs
 // A slice's records: n_wg runs of `cap` records; in the counter's coordinates every run takes capr = cap rounded up to
 // whole steps, so no step crosses runs.
 #ifndef NTE_PROBE_TPB
-#define NTE_PROBE_TPB 1024
+#define NTE_PROBE_TPB 512
 #endif
 constexpr int PROBE_TPB = NTE_PROBE_TPB;
 constexpr int PROBE_WAVES = PROBE_TPB / 64;

@@ -545,6 +545,11 @@ main(int argc, char** argv)
 				}
 				sq.clear();
 			}
+			if (scan.io_error()) {
+				// (a partition computed from half a draft would differ between the shards)
+				fprintf(stderr, PROGRAM ": error: `%s': %s\n", draft.c_str(), scan.io_error_text().c_str());
+				fatal();
+			}
 		}
 		std::vector<uint32_t> order(lens.size());
 		for (size_t i = 0; i < order.size(); i++) {

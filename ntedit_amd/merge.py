@@ -10,13 +10,17 @@ import sys
 from .dist import _copy_range
 
 
-def _header_bytes(path, is_header):
+# what ntedit_hip_write_tsv_header / ntedit_hip_write_vcf_header put in front of the records (host/render.cpp):
+# counted in lines, never sniffed by prefix -- a contig may be called "#chr1"
+TSV_HEADER_LINES = 1
+VCF_HEADER_LINES = 7
+
+
+def _header_bytes(path, n_lines):
     n = 0
     with open(path, "rb") as f:
-        for line in f:
-            if not is_header(line):
-                break
-            n += len(line)
+        for _ in range(n_lines):
+            n += len(f.readline())
     return n
 
 
@@ -24,8 +28,8 @@ def merge_cli_shards(out_prefix, shard_prefixes):
     entries = []  # (ordinal, shard, fa off, tsv off, vcf off, sizes)
     for s, pre in enumerate(shard_prefixes):
         off = [0,
-               _header_bytes(pre + "_changes.tsv", lambda l: l.startswith(b"ID\tbpPosition+1\t")),
-               _header_bytes(pre + "_variants.vcf", lambda l: l.startswith(b"#"))]
+               _header_bytes(pre + "_changes.tsv", TSV_HEADER_LINES),
+               _header_bytes(pre + "_variants.vcf", VCF_HEADER_LINES)]
         with open(pre + ".index.tsv", "rb") as f:
             for line in f:
                 if line.startswith(b"#"):
@@ -43,7 +47,7 @@ def merge_cli_shards(out_prefix, shard_prefixes):
     outs = [open(out_prefix + suf, "wb") for suf in suffixes]
     try:
         first = shard_prefixes[0]
-        for j, hdr in ((1, lambda l: l.startswith(b"ID\tbpPosition+1\t")), (2, lambda l: l.startswith(b"#"))):
+        for j, hdr in ((1, TSV_HEADER_LINES), (2, VCF_HEADER_LINES)):
             n = _header_bytes(first + suffixes[j], hdr)
             _copy_range(ins[0][j], outs[j], n)
         for _, s, off, sz in entries:

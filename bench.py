@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--no-weak", action="store_true", help="skip the weak-scaling leg at N>1")
     ap.add_argument("--e2e-bgzf", action="store_true", help="also run the end-to-end region on a BGZF-compressed draft")
     ap.add_argument("--no-regions", action="store_true", help="skip the host-buffer and end-to-end regions (N=1)")
+    ap.add_argument("--snv", action="store_true",
+                    help="N=1 side line: -s 1 (every position re-assessed, ntedit.cpp:1806,1865; -i/-d 0)")
+    ap.add_argument("--counting", action="store_true",
+                    help="N=1 side line: a counting filter of --filter-bytes 8-bit counters (synthetic contents), -p 2")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="ntedit_hip_set_tuning knob (repeatable; none of them changes a result)")
     ap.add_argument("--shared-filter", action="store_true",
@@ -372,7 +376,12 @@ def main():
         key, _, val = kv.partition("=")
         pol.set_tuning(key, int(val))
     pol._lib.ntedit_hip_bind_near_device(local)  # this rank's host side on the socket its GPU hangs off
-    pol.set_params(ntedit_amd.default_params(start_grid=args.start_grid, screen_mode=args.screen_mode))
+    mode_kw = {}
+    if args.snv:
+        mode_kw = dict(snv=1, max_insertions=0, max_deletions=0)
+    if (args.snv or args.counting) and world > 1:
+        raise SystemExit("--snv / --counting are single-GPU side lines")
+    pol.set_params(ntedit_amd.default_params(start_grid=args.start_grid, screen_mode=args.screen_mode, **mode_kw))
     t_setup = time.perf_counter()
     # the same truth genome and the same draft on every rank; rank 0 builds the filter and broadcasts it (RCCL)
     shared = world > 1 or args.shared_filter
@@ -381,9 +390,16 @@ def main():
         build = "insert" if rank == 0 else False
     else:
         build = "alloc"
-    job = SyntheticJob(pol, args.bases, k=args.k, hash_num=args.hashes, filter_bytes=args.filter_bytes,
+    job = SyntheticJob(pol, args.bases, k=args.k, hash_num=args.hashes,
+                       filter_bytes=args.filter_bytes // 8 if args.counting else args.filter_bytes,
                        seed=20251031, draft_seed=20251032, device=dev, build_filter=build,
                        contig_len=args.contig_len)
+    counters = None
+    if args.counting:
+        # the plain filter's bit slots become 8-bit counters (1..4 for every truth k-mer); -p 2
+        from ntedit_amd.synth import counting_filter_from_plain
+        counters = counting_filter_from_plain(pol, args.k, args.hashes, device=dev)
+        pol.set_params(ntedit_amd.default_params(start_grid=args.start_grid, screen_mode=args.screen_mode, min_threshold=2))
     if shared:
         ndist.broadcast_filter(fbuf, src=0)
     torch.cuda.synchronize()
@@ -462,9 +478,10 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = total_bases * args.steps / elapsed / 1e6
         # Screening = the dominant part of a step.  Direct path: ONE kernel (k_screen), algorithmic bytes per k-mer
-        # start = h filter bytes + 1 draft byte + 1/8 bitmap byte.  Binned path: four kernels per record
-        # chunk; the dominant one is k_bin_probe, whose share of those bytes is the h filter bytes + the bitmap
-        # byte/8 (the draft byte is read by the partition kernels); the per-launch figures are what rocprofv3's
+        # start = h filter bytes + 1 draft byte + 1/8 bitmap byte.  Binned path: the partition kernel and the
+        # probe kernel, once per record chunk (ONE chunk at 3 Gbp); the dominant one is k_bin_probe, whose share of
+        # those bytes is the h filter bytes + the bitmap byte/8 (the draft byte is read by the partition kernel);
+        # the per-launch figures are what rocprofv3's
         # kernel stats average over.  `pipeline` prices the whole screening at the full 4.125 B per k-mer start.
         step_screen = sum(screen_ms) / len(screen_ms)
         if binned:
@@ -497,7 +514,9 @@ def main():
                              " of %d bp" % args.contig_len if args.contig_len else " 50 kbp-50 Mbp",
                              args.k, args.filter_bytes, args.hashes,
                              "screen kernel only" if args.screen_only else
-                             "screen + event extraction + event machine + edit records to host"),
+                             "screen + event extraction + event machine + edit records to host") +
+                            (", SNV mode (-s 1, -i 0 -d 0)" if args.snv else "") +
+                            (", COUNTING filter (8-bit counters, synthetic contents 1..4, -p 2)" if args.counting else ""),
                 "total_bases": total_bases,
                 "parallelism": "ONE draft sharded over %d rank(s) by bases (LPT over pieces; %d contig(s) cut into "
                                "segments), filter broadcast once over RCCL (untimed)" % (world, n_cut),
@@ -517,7 +536,7 @@ def main():
                 "launches_per_step": launches[0],
                 "probes_per_s": round(args.hashes * my_bytes / (step_screen * 1e-3), 0),
                 "pipeline": {
-                    "kernels": ["k_wc_count", "k_wc_scan", "k_wc_scatter", "k_bin_probe"] if binned else ["k_screen"],
+                    "kernels": ["k_wc_scatter", "k_bin_probe", "k_ovf_probe"] if binned else ["k_screen"],
                     "ms_per_step": round(step_screen, 3),
                     "algorithmic_bytes_per_step": int((args.hashes + 1 + 0.125) * my_bytes),
                     "achieved": round((args.hashes + 1 + 0.125) * my_bytes / (step_screen * 1e-3) / 1e9, 2),

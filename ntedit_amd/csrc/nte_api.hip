@@ -92,7 +92,8 @@ struct ntedit_hip_ctx
 	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters, deferred;
 	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps, ws_win;
 	DevBuf offs, lens;
-	DevBuf bin_records, bin_fill, bin_ctl, bin_ovf, bin_lost;
+	DevBuf bin_records[2], bin_fill[2], bin_ctl[2], bin_ovf[2], bin_lost; // (two sets: chunk j + 1 is partitioned while chunk j is probed)
+	hipStream_t stream3 = nullptr;    // the probe stage of the binned screening when it overlaps the partition stage
 	bool bin_fallback = false;        // an overflow list overflowed: this context screens with the direct kernel from now on
 	struct Tuning                     // ntedit_hip_set_tuning(): test / tuning knobs, none of which can change a result
 	{
@@ -108,6 +109,7 @@ struct ntedit_hip_ctx
 		u32 no_rounds = 0, no_early_copy = 0, no_lds_ws = 0;
 		u32 probe_parts_log2 = 0; // the probe stage walks every slice 2^n times, one part of it per walk
 		u32 records_uncached = 0; // the screening records in memory the L2 does not keep (experiments)
+		u32 bin_overlap = 0;      // partition chunk j + 1 while chunk j is probed (two record buffers, a second stream)
 	} tune;
 	DevBuf ev_cover, ev_before, ev_flags, ev_list, ev_bmax; // event rounds
 	u32 cu_count = 256;
@@ -512,33 +514,35 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		pos_end = n;
 	}
 	const u64 span = pos_end - pos_begin;
-	// record chunks: the whole range at once when its records take no more than 40 % of the HBM that is free right
-	// now (3 Gbp at h = 3: 76 GB), else as few equal chunks as that allows
+	// Record chunks: the whole range at once when its records take no more than 40 % of the HBM that is free right
+	// now (3 Gbp at h = 3: 74.5 GB), else as few equal chunks as that allows.  (Partitioning chunk j + 1 on this stream
+	// while chunk j is probed on another -- "bin_overlap", two record buffers -- was built and measured: the two kernels
+	// do run together, but the probe stage saturates the L2 the partition stage's stores have to pass through; the
+	// partition of a 750 M k-mer chunk takes 21 ms next to a probe instead of 12.7 ms alone and the step gains nothing.)
 	const u64 unit = (u64)WC_WTILE * WC_WAVES; // chunk sizes: whole workgroup rounds (also a multiple of 16 bytes)
-	u64 chunk = (span + unit - 1) / unit * unit;
+	const bool overlap = c->tune.bin_overlap && span >= (1ULL << 28);
+	u64 parts = overlap ? 4 : 1;
 	{
 		size_t free_b = 0, total_b = 0;
 		u64 room = ~0ULL;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-			room = (u64)(free_b + c->bin_records.cap) * 2 / 5;
+			room = (u64)(free_b + c->bin_records[0].cap + c->bin_records[1].cap) / 5 * (overlap ? 1 : 2);
 		}
-		u64 parts = 1;
 		while (parts < 4096 && plan_wc(c, (span + parts - 1) / parts, f.hash_num, n_slices).record_bytes > room) {
 			parts++;
 		}
-		if (parts > 1) {
-			chunk = ((span + parts - 1) / parts + unit - 1) / unit * unit;
-		}
-		if (plan_wc(c, chunk, f.hash_num, n_slices).record_bytes > room) {
+		if (plan_wc(c, (span + parts - 1) / parts, f.hash_num, n_slices).record_bytes > room) {
 			return fail(c, NTEDIT_E_DEVICE, "not enough device memory for the screening records");
 		}
 	}
+	u64 chunk = ((span + parts - 1) / parts + unit - 1) / unit * unit;
 	if (c->tune.bin_chunk) { // tests: force several chunks
 		const u64 v = c->tune.bin_chunk / unit * unit;
 		if (v >= unit && v < chunk) {
 			chunk = v;
 		}
 	}
+	const bool two = overlap && chunk < span; // two buffer sets, two streams
 	const WcPlan plan0 = plan_wc(c, span < chunk ? span : chunk, f.hash_num, n_slices);
 	const u32 ovf_cap = 1u << 22; // 64 MiB of overflow entries per chunk; beyond that the direct kernel takes over
 	const u32 parts_log2 = c->tune.probe_parts_log2;
@@ -550,23 +554,37 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		}
 		HIP_TRY(c, hipMemsetAsync(c->bin_lost.p, 0, 4, stream));
 	}
-	if ((rc = ensure(c, c->bin_records, plan0.record_bytes)) ||
-	    (rc = ensure(c, c->bin_fill, (size_t)n_slices * plan0.n_wg * 4)) ||
-	    (rc = ensure(c, c->bin_ctl, (ctl_words + 8) * 4)) ||
-	    (rc = ensure(c, c->bin_ovf, (size_t)ovf_cap * sizeof(WcOvf)))) {
-		return rc;
+	for (int q = 0; q < (two ? 2 : 1); q++) {
+		if ((rc = ensure(c, c->bin_records[q], plan0.record_bytes)) ||
+		    (rc = ensure(c, c->bin_fill[q], (size_t)n_slices * plan0.n_wg * 4)) ||
+		    (rc = ensure(c, c->bin_ctl[q], (ctl_words + 8) * 4)) ||
+		    (rc = ensure(c, c->bin_ovf[q], (size_t)ovf_cap * sizeof(WcOvf)))) {
+			return rc;
+		}
 	}
-	u32* d_ctl = (u32*)c->bin_ctl.p;
-	u32* d_ovf_count = d_ctl + ctl_words; // (+ 3 words of NTE_WC_STATS counters)
+	if (two && !c->stream3) {
+		HIP_TRY(c, hipStreamCreate(&c->stream3));
+	}
+	hipStream_t pstream = two ? c->stream3 : stream;
 	{
 		// the probe stage ORs into the bitmap: clear the words of the range first
 		const u64 w0 = pos_begin / 64, w1 = (pos_end + 63) / 64 < n_words ? (pos_end + 63) / 64 : n_words;
 		HIP_TRY(c, hipMemsetAsync(d_bitmap + w0, 0, (w1 - w0) * 8, stream));
 	}
+	const u64 n_chunks = (span + chunk - 1) / chunk;
+	// per chunk: [0] partition begins, [1] partitioned, [2] probe begins, [3] probed (timed; [1] and [3] also order the streams)
+	while (c->bin_ev.size() < 4 * (size_t)n_chunks) {
+		hipEvent_t e;
+		HIP_TRY(c, hipEventCreate(&e));
+		c->bin_ev.push_back(e);
+	}
 	u32 chunk_no = 0;
 	for (u64 begin = pos_begin; begin < pos_end; begin += chunk, chunk_no++) {
 		const u64 end = begin + chunk < pos_end ? begin + chunk : pos_end;
 		const WcPlan plan = plan_wc(c, end - begin, f.hash_num, n_slices);
+		const int q = two ? (int)(chunk_no & 1) : 0;
+		u32* d_ctl = (u32*)c->bin_ctl[q].p;
+		u32* d_ovf_count = d_ctl + ctl_words; // (+ words of NTE_WC_STATS counters)
 		WcArgs w;
 		w.b.seq = d_seq;
 		w.b.n = n;
@@ -577,21 +595,16 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		w.b.tabs = c->d_tab;
 		w.b.n_slices = n_slices;
 		w.b.slice_log2 = slog;
-		w.b.records = (u64*)c->bin_records.p;
-		w.fill = (u32*)c->bin_fill.p;
-		w.ovf = (WcOvf*)c->bin_ovf.p;
+		w.b.records = (u64*)c->bin_records[q].p;
+		w.fill = (u32*)c->bin_fill[q].p;
+		w.ovf = (WcOvf*)c->bin_ovf[q].p;
 		w.ovf_count = d_ovf_count;
 		w.ovf_cap = ovf_cap;
 		w.n_wg = plan.n_wg;
 		w.cap = plan.cap;
 		w.n_wtiles = plan.n_wtiles;
 		w.wcodes = (u32)wc_codes_bytes(c->dp.k);
-		while (c->bin_ev.size() < 3 * (size_t)(chunk_no + 1)) {
-			hipEvent_t e;
-			HIP_TRY(c, hipEventCreate(&e));
-			c->bin_ev.push_back(e);
-		}
-		hipEvent_t* tev = &c->bin_ev[3 * (size_t)chunk_no];
+		hipEvent_t* tev = &c->bin_ev[4 * (size_t)chunk_no];
 		if (c->h2d_piece_bytes) {
 			// the chunk's bases (+ the k-1 behind its end) must have arrived
 			u64 piece = (end + SCREEN_TILE) / c->h2d_piece_bytes;
@@ -600,16 +613,24 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 			}
 			HIP_TRY(c, hipStreamWaitEvent(stream, c->h2d_ev[piece], 0));
 		}
+		if (two && chunk_no >= 2) {
+			// this buffer set was last read by the probe of chunk_no - 2
+			HIP_TRY(c, hipStreamWaitEvent(stream, c->bin_ev[4 * (size_t)(chunk_no - 2) + 3], 0));
+		}
 		HIP_TRY(c, hipMemsetAsync(d_ctl, 0, (ctl_words + 8) * 4, stream));
 		HIP_TRY(c, hipEventRecord(tev[0], stream));
 		if ((rc = run_wc_partition(c, stream, w))) {
 			return rc;
 		}
 		HIP_TRY(c, hipEventRecord(tev[1], stream));
+		if (two) {
+			HIP_TRY(c, hipStreamWaitEvent(pstream, tev[1], 0));
+		}
+		HIP_TRY(c, hipEventRecord(tev[2], pstream));
 		ProbeArgs pa;
 		pa.filter = f.data;
-		pa.records = (const u64*)c->bin_records.p;
-		pa.fill = (const u32*)c->bin_fill.p;
+		pa.records = (const u64*)c->bin_records[q].p;
+		pa.fill = (const u32*)c->bin_fill[q].p;
 		pa.n_slices = n_slices << parts_log2;
 		pa.slog = slog;
 		pa.parts_log2 = parts_log2;
@@ -620,18 +641,18 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		pa.force_xcc = c->tune.force_xcc ? c->tune.force_xcc - 1 : PROBE_XCC_ANY;
 		pa.counting = f.counting;
 		pa.count_lo = c->dp.min_thr > 1 ? c->dp.min_thr : 1;
-		hipLaunchKernelGGL(k_bin_probe, dim3(c->cu_count * (2048 / PROBE_TPB)), dim3(PROBE_TPB), 0, stream, pa);
-		hipLaunchKernelGGL(k_ovf_probe, dim3(64), dim3(256), 0, stream, f.data, (const WcOvf*)c->bin_ovf.p, (const u32*)d_ovf_count, ovf_cap, slog,
+		hipLaunchKernelGGL(k_bin_probe, dim3(c->cu_count * (2048 / PROBE_TPB)), dim3(PROBE_TPB), 0, pstream, pa);
+		hipLaunchKernelGGL(k_ovf_probe, dim3(64), dim3(256), 0, pstream, f.data, (const WcOvf*)c->bin_ovf[q].p, (const u32*)d_ovf_count, ovf_cap, slog,
 		                   (u32*)d_bitmap, (u32)f.counting, pa.count_lo);
-		HIP_TRY(c, hipGetLastError());
-		HIP_TRY(c, hipEventRecord(tev[2], stream));
 		// overflow entries that did not fit are lost probes: the caller must look at this before it trusts the bitmap
-		hipLaunchKernelGGL(k_ovf_check, dim3(1), dim3(1), 0, stream, (const u32*)d_ovf_count, ovf_cap, (u32*)c->bin_lost.p);
+		hipLaunchKernelGGL(k_ovf_check, dim3(1), dim3(1), 0, pstream, (const u32*)d_ovf_count, ovf_cap, (u32*)c->bin_lost.p);
+		HIP_TRY(c, hipGetLastError());
+		HIP_TRY(c, hipEventRecord(tev[3], pstream));
 		if (c->tune.bin_timing) {
-			HIP_TRY(c, hipStreamSynchronize(stream));
+			HIP_TRY(c, hipStreamSynchronize(pstream));
 			float t_part = 0.f, t_probe = 0.f;
 			(void)hipEventElapsedTime(&t_part, tev[0], tev[1]);
-			(void)hipEventElapsedTime(&t_probe, tev[1], tev[2]);
+			(void)hipEventElapsedTime(&t_probe, tev[2], tev[3]);
 			u32 ovf_n = 0;
 			(void)hipMemcpy(&ovf_n, d_ovf_count, 4, hipMemcpyDeviceToHost);
 #ifdef NTE_WC_STATS
@@ -640,8 +661,14 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 			fprintf(stderr, "[ntedit_hip] scatter: %u wavefront rounds, %u extra passes, %u lanes with a record that found its ring half taken, %u deferred group flushes that had to wait again\n",
 			        stats[1], stats[0], stats[2], stats[3]);
 #endif
-			fprintf(stderr, "[ntedit_hip] binned chunk %llu k-mers, %u slices of 2^%u bits, %u x %u-record runs per slice (%.2f GB), %u overflow records: partition %.3f ms, probe %.3f ms\n",
+			fprintf(stderr, "[ntedit_hip] binned chunk %llu k-mers, %u slices of 2^%u bits, %u x %u-record runs per slice (%.2f GB), %u overflow records: partition %.3f ms, probe %.3f ms (stages timed alone)\n",
 			        (unsigned long long)(end - begin), n_slices, slog, plan.n_wg, plan.cap, plan.record_bytes / 1e9, ovf_n, t_part, t_probe);
+		}
+	}
+	if (two) {
+		// everything the caller queues on `stream` behind this call sees the complete bitmap
+		for (u32 j = chunk_no >= 2 ? chunk_no - 2 : 0; j < chunk_no; j++) {
+			HIP_TRY(c, hipStreamWaitEvent(stream, c->bin_ev[4 * (size_t)j + 3], 0));
 		}
 	}
 	c->bin_chunks_last = chunk_no;
@@ -756,7 +783,7 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 	}
 	DevBuf* bufs[] = { &c->seq,      &c->bitmap,   &c->block_counts, &c->block_offsets, &c->events,
 		               &c->first_chunk, &c->arena, &c->counters, &c->deferred,     &c->ws_nodes,      &c->ws_ov_pos,
-		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->bin_records, &c->bin_fill, &c->bin_ctl, &c->bin_ovf, &c->bin_lost, &c->ev_cover, &c->ev_before, &c->ev_flags, &c->ev_list, &c->ev_bmax,       &c->offs,          &c->lens };
+		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->bin_records[0], &c->bin_records[1], &c->bin_fill[0], &c->bin_fill[1], &c->bin_ctl[0], &c->bin_ctl[1], &c->bin_ovf[0], &c->bin_ovf[1], &c->bin_lost, &c->ev_cover, &c->ev_before, &c->ev_flags, &c->ev_list, &c->ev_bmax,       &c->offs,          &c->lens };
 	for (DevBuf* b : bufs) {
 		release(*b);
 	}
@@ -780,6 +807,10 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 	}
 	for (auto& e : c->bin_ev) {
 		(void)hipEventDestroy(e);
+	}
+	if (c->stream3) {
+		(void)hipStreamSynchronize(c->stream3);
+		(void)hipStreamDestroy(c->stream3);
 	}
 	if (c->stream2) {
 		(void)hipStreamSynchronize(c->stream2);
@@ -1900,8 +1931,8 @@ PolishRun::finish()
 		r->st.screen_launches = c->bin_chunks_last;
 		for (u32 q = 0; q < c->bin_chunks_last; q++) {
 			float tp = 0.f, tq = 0.f;
-			(void)hipEventElapsedTime(&tp, c->bin_ev[3 * q], c->bin_ev[3 * q + 1]);
-			(void)hipEventElapsedTime(&tq, c->bin_ev[3 * q + 1], c->bin_ev[3 * q + 2]);
+			(void)hipEventElapsedTime(&tp, c->bin_ev[4 * q], c->bin_ev[4 * q + 1]);
+			(void)hipEventElapsedTime(&tq, c->bin_ev[4 * q + 2], c->bin_ev[4 * q + 3]);
 			r->st.ms_partition += tp;
 			r->st.ms_probe += tq;
 		}
@@ -2421,11 +2452,15 @@ ntedit_hip_set_tuning(ntedit_hip_ctx* c, const char* key, uint64_t value)
 		t.no_lds_ws = (u32)value;
 	} else if (k == "probe_parts_log2") {
 		t.probe_parts_log2 = (u32)value < 4 ? (u32)value : 3;
+	} else if (k == "bin_overlap") {
+		t.bin_overlap = (u32)value;
 	} else if (k == "records_uncached") {
 		t.records_uncached = (u32)value;
-		if (c->bin_records.uncached != (value != 0)) {
-			release(c->bin_records);
-			c->bin_records.uncached = value != 0;
+		for (int q = 0; q < 2; q++) {
+			if (c->bin_records[q].uncached != (value != 0)) {
+				release(c->bin_records[q]);
+				c->bin_records[q].uncached = value != 0;
+			}
 		}
 	} else if (k == "bin_fallback") {
 		c->bin_fallback = value != 0;

@@ -130,3 +130,36 @@ def test_two_rank_bad_cuts_are_caught_and_rerun(tmp_path, oracle_build):
     H.run_oracle(case["draft"], case["bf"], H.default_params(), str(tmp_path / "o"))
     stats = _two_ranks(tmp_path, case, ["3000", "blind"])
     assert sum(s[2] for s in stats) > 0  # some cuts were rejected
+
+
+def test_merge_cli_shards_counts_header_lines(tmp_path):
+    """the gather of `ntedit --shard` outputs must not sniff headers by prefix -- a contig may be called
+    "#chr1", and its VCF rows start with '#' like the header lines do"""
+    from ntedit_amd.merge import merge_cli_shards, TSV_HEADER_LINES, VCF_HEADER_LINES
+    vcf_hdr = b"".join(b"##h%d\n" % i for i in range(VCF_HEADER_LINES - 1)) + b"#CHROM\tPOS\n"
+    tsv_hdr = b"ID\tbpPosition+1\tOriginalBase\n"
+    assert TSV_HEADER_LINES == 1
+    shards = []
+    # shard 0 holds contigs 0 and 2, shard 1 holds contig 1; contig 0 is called "#c0"
+    content = {0: (b">#c0\nACGT\n", b"#c0\t3\tA\n", b"#c0\t3\t.\tA\tC\n"),
+               1: (b">c1\nGG\n", b"c1\t1\tG\n", b"c1\t1\t.\tG\tT\n"),
+               2: (b">c2\nTTT\n", b"", b"")}
+    for s, ords in enumerate(([0, 2], [1])):
+        pre = str(tmp_path / ("s%d" % s))
+        with open(pre + "_edited.fa", "wb") as fa, open(pre + "_changes.tsv", "wb") as tsv, \
+                open(pre + "_variants.vcf", "wb") as vcf, open(pre + ".index.tsv", "wb") as idx:
+            tsv.write(tsv_hdr)
+            vcf.write(vcf_hdr)
+            idx.write(b"# ordinal fa tsv vcf\n")
+            for o in ords:
+                f, t, v = content[o]
+                fa.write(f)
+                tsv.write(t)
+                vcf.write(v)
+                idx.write(b"%d %d %d %d\n" % (o, len(f), len(t), len(v)))
+        shards.append(pre)
+    out = str(tmp_path / "out")
+    assert merge_cli_shards(out, shards) == 3
+    assert open(out + "_edited.fa", "rb").read() == b"".join(content[o][0] for o in range(3))
+    assert open(out + "_changes.tsv", "rb").read() == tsv_hdr + b"".join(content[o][1] for o in range(3))
+    assert open(out + "_variants.vcf", "rb").read() == vcf_hdr + b"".join(content[o][2] for o in range(3))

@@ -525,7 +525,7 @@ def test_counting_filter_250mbp_every_contig(tmp_path, oracle_build, capsys):
         pol.set_params(ntedit_amd.default_params(min_threshold=2))
         st, host, names = _compare_every_contig(pol, job, tmp_path, "cbf250", capsys, counting=True, min_threshold=2)
         assert st.screen_binned
-        assert st.substitutions > 0.5e-3 * job.n_bases
+        assert st.substitutions > 1e-4 * job.n_bases  # (a quarter of the truth k-mers have count 1 < -p 2: many positions cannot be fixed)
         del counters
     finally:
         pol.close()

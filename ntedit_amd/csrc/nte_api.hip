@@ -516,12 +516,18 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 	const u64 span = pos_end - pos_begin;
 	// Record chunks: the whole range at once when its records take no more than 40 % of the HBM that is free right
 	// now (3 Gbp at h = 3: 74.5 GB), else as few equal chunks as that allows.  (Partitioning chunk j + 1 on this stream
-	// while chunk j is probed on another -- "bin_overlap", two record buffers -- was built and measured: the two kernels
-	// do run together, but the probe stage saturates the L2 the partition stage's stores have to pass through; the
-	// partition of a 750 M k-mer chunk takes 21 ms next to a probe instead of 12.7 ms alone and the step gains nothing.)
+	// while chunk j is probed on another -- "bin_overlap", two record buffers, the partition kernel held to 96 VGPRs so
+	// that probe wavefronts fit next to it -- was built and measured on the 3 Gbp workload: 113.7 ms in four chunks
+	// against 109-115 ms for chunks one after the other and 103 ms for ONE chunk; the sum of the stages' own times.  Both
+	// stages lean on the L2: the probe stage saturates it, the partition stage sends 4.5e9 16-byte stores through it.)
 	const u64 unit = (u64)WC_WTILE * WC_WAVES; // chunk sizes: whole workgroup rounds (also a multiple of 16 bytes)
 	const bool overlap = c->tune.bin_overlap && span >= (1ULL << 28);
 	u64 parts = overlap ? 4 : 1;
+	if (c->h2d_piece_bytes && span >= (1ULL << 28)) {
+		// the batch is still crossing PCIe: in several record chunks the screening of the bases that have arrived runs
+		// under the copy of the rest (every chunk waits for its own pieces only)
+		parts = span >> 28 < 6 ? span >> 28 : 6;
+	}
 	{
 		size_t free_b = 0, total_b = 0;
 		u64 room = ~0ULL;

@@ -1288,6 +1288,8 @@ struct PolishRun
 	int begin_attempt();
 	int launch_screening(int attempt);
 	void launch_wave_pass(MachineArgs a, const u32* list, u32 count);
+	int extract_events(size_t j, u64* n_ev_out, u64** d_events_out, u32** d_first_out);
+	int machine_setup(u64 n_ev, u64* d_events, u32* d_first, MachineArgs* out, u64* blocks_out, size_t* dyn_lds_out);
 	int run_chunk_events(size_t j);
 	int collect(bool* redo);
 	int finish();
@@ -1527,18 +1529,19 @@ PolishRun::launch_wave_pass(MachineArgs a, const u32* list, u32 count)
 	launch_k_machine_wave((unsigned)b2, dyn2, sB, a);
 }
 
-// stream B, chunk j: as soon as its screening is done
+// stream B, chunk j, as soon as its screening is done: absent bitmap -> ordered event list (count, single-workgroup
+// scan, write).  *n_ev_out = its events, written behind those of the earlier chunks (d_events / d_first).
 int
-PolishRun::run_chunk_events(size_t j)
+PolishRun::extract_events(size_t j, u64* n_ev_out, u64** d_events_out, u32** d_first_out)
 {
 	int rc;
+	*n_ev_out = 0;
 	const Chunk& ch = chunks[j];
 	HIP_TRY(c, hipStreamWaitEvent(sB, c->chunk_ev[2 * j + 1], 0));
 	if (first_b) {
 		HIP_TRY(c, hipEventRecord(c->ev[2], sB));
 		first_b = false;
 	}
-	// ---- absent bitmap -> ordered event list (count, single-workgroup scan, write)
 	const u64 w0 = ch.b0 / 64, w1 = (ch.b1 + 63) / 64;
 	const u64 n_sblocks = (w1 - w0 + ST_TPB - 1) / ST_TPB;
 	if (n_sblocks == 0) {
@@ -1591,8 +1594,17 @@ PolishRun::run_chunk_events(size_t j)
 	hipLaunchKernelGGL(
 	    k_write_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_bitmap, w0, w1, ch.b0, ch.b1, grid_lo, grid,
 	    (const unsigned long long*)c->block_offsets.p, d_events);
+	*n_ev_out = n_ev;
+	*d_events_out = d_events;
+	*d_first_out = d_first;
+	return 0;
+}
 
-	// ---- the machine's launch arguments and per-thread workspace
+// the machine's launch arguments and per-thread workspace for a chunk of n_ev events
+int
+PolishRun::machine_setup(u64 n_ev, u64* d_events, u32* d_first, MachineArgs* out, u64* blocks_out, size_t* dyn_lds_out)
+{
+	int rc;
 	const u64 max_threads = (u64)c->cu_count * 2048;
 	u64 threads = n_ev < max_threads ? n_ev : max_threads;
 	const u64 blocks = (threads + MACHINE_TPB - 1) / MACHINE_TPB;
@@ -1646,6 +1658,30 @@ PolishRun::run_chunk_events(size_t j)
 	a.work_counter = (u32*)((char*)c->counters.p + 60);
 	if (n_ch != 1) {
 		a.p.event_budget = 0; // (parked events are re-run per batch: single-chunk batches only)
+	}
+	*out = a;
+	*blocks_out = blocks;
+	*dyn_lds_out = dyn_lds;
+	return 0;
+}
+
+// stream B, chunk j: its events through the event machine, in rounds
+int
+PolishRun::run_chunk_events(size_t j)
+{
+	int rc;
+	const Chunk& ch = chunks[j];
+	u64 n_ev = 0;
+	u64* d_events = nullptr;
+	u32* d_first = nullptr;
+	if ((rc = extract_events(j, &n_ev, &d_events, &d_first)) || n_ev == 0) {
+		return rc;
+	}
+	MachineArgs a;
+	u64 blocks = 0;
+	size_t dyn_lds = 0;
+	if ((rc = machine_setup(n_ev, d_events, d_first, &a, &blocks, &dyn_lds))) {
+		return rc;
 	}
 
 	// ---- rounds (see "event rounds" in nte_kernels.hip): primaries, then the secondaries their

@@ -353,7 +353,7 @@ void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
  * list), "bin_fallback" (1: direct kernel from now on, as after a lost overflow), "bin_overlap" (partition a record chunk while the previous one is probed), "probe_parts_log2",
  * "force_xcc" (x + 1: the probe
  * stage behaves as if every wavefront ran on XCD x), "bin_timing", "chunk_bytes" (pipeline chunk size), "h2d_piece"
- * (bytes per host-to-device piece), "inline_tries", "screen_lds_pad", "no_rounds", "no_early_copy", "no_lds_ws".
+ * (bytes per host-to-device piece), "inline_tries", "screen_lds_pad", "no_rounds", "force_rounds", "no_early_copy", "no_lds_ws".
  * The library reads two environment variables only: NTEDIT_HIP_DEBUG (diagnostics on stderr) and
  * NTEDIT_HIP_NO_BIND (see ntedit_hip_bind_near_device). */
 int ntedit_hip_set_tuning(ntedit_hip_ctx* ctx, const char* key, uint64_t value);

@@ -107,6 +107,7 @@ struct ntedit_hip_ctx
 		u32 inline_tries = ~0u;  // candidates of an indel sweep the deferring launch tries itself (~0: default)
 		u32 screen_lds_pad = 0;  // LDS pad of the direct screening kernel (occupancy experiments)
 		u32 no_rounds = 0, no_early_copy = 0, no_lds_ws = 0;
+		u32 force_rounds = 0;     // event rounds whatever the number of events (tests: small inputs)
 		u32 probe_parts_log2 = 0; // the probe stage walks every slice 2^n times, one part of it per walk
 		u32 records_uncached = 0; // the screening records in memory the L2 does not keep (experiments)
 		u32 bin_overlap = 0;      // partition chunk j + 1 while chunk j is probed (two record buffers, a second stream)
@@ -1687,7 +1688,11 @@ PolishRun::run_chunk_events(size_t j)
 	// ---- rounds (see "event rounds" in nte_kernels.hip): primaries, then the secondaries their
 	// primary's run does not overtake, then -- practically never -- whatever a verification rejects.
 	// SNV mode runs everything in one round.
-	const bool rounds = !c->dp.snv && n_ev < 0xFFFFFF00ull && !c->tune.no_rounds;
+	// Rounds pay when the events outnumber the machine's threads several times over (3 Gbp: 4.4 M events, 42 ms against 55
+	// in one round); a small batch is bound by the latency of its slowest events, which every round pays again
+	// (375 Mbp, 0.44 M events: 9.0 ms in rounds, 7.0 ms in one; break-even at 1.8 M events).
+	const bool rounds = !c->dp.snv && n_ev < 0xFFFFFF00ull && !c->tune.no_rounds &&
+	                    (c->tune.force_rounds || n_ev >= (u64)c->cu_count * 8192);
 	u32* d_list = nullptr;
 	u64* d_before = nullptr;
 	u64* d_bmax = nullptr;
@@ -2486,6 +2491,8 @@ ntedit_hip_set_tuning(ntedit_hip_ctx* c, const char* key, uint64_t value)
 		c->dp_valid = false;
 	} else if (k == "screen_lds_pad") {
 		t.screen_lds_pad = (u32)value;
+	} else if (k == "force_rounds") {
+		t.force_rounds = (u32)value;
 	} else if (k == "no_rounds") {
 		t.no_rounds = (u32)value;
 	} else if (k == "no_early_copy") {

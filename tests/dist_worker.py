@@ -30,8 +30,9 @@ class HostsimBackend:
             return np.zeros((len(blob) + 63) // 64, dtype=np.uint64)
         return H.oracle_screen(blob, self.bf)
 
-    def _run(self, entries, segs, prefix, covers=None, sizes=None):
+    def _run(self, entries, segs, prefix, covers=None, sizes=None, cuts_ok=None):
         lib = H.hostsim_lib()
+        lib.hostsim_set_cuts_ok(cuts_ok.ctypes.data_as(ctypes.c_void_p) if cuts_ok is not None else None)
         arr = (Segment * max(len(entries), 1))()
         for i, (off, halo, flags) in enumerate(segs):
             arr[i].pos_offset, arr[i].halo, arr[i].flags = off, halo, flags
@@ -57,10 +58,16 @@ class HostsimBackend:
         n = len(entries)
         segs = [e[2] for e in entries]
         covers = np.zeros(max(n, 1), dtype=np.uint32)
-        rc = self._run(entries, segs, None, covers=covers)  # (no output: only the cover ends; -7 = some cut is bad)
+        ok = np.ones(max(n, 1), dtype=np.uint8)
+        # (no output: the renderer's verdict -- -7 = some cut is bad -- and the predicate the product's driver asks
+        # before it writes anything, ntedit_hip_result_cuts_ok; they must agree)
+        rc = self._run(entries, segs, None, covers=covers, cuts_ok=ok)
         assert rc in (0, -7), rc
-        bad = [i for i, (_, seq, (off, halo, flags)) in enumerate(entries) if halo and covers[i] > len(seq) - halo]
+        bad = [i for i in range(n) if not ok[i]]
         assert (rc == -7) == bool(bad), (rc, bad)
+        # every cut the run ends behind is bad (the cover end alone is the weaker test the driver used to apply)
+        weak = [i for i, (_, seq, (off, halo, flags)) in enumerate(entries) if halo and covers[i] > len(seq) - halo]
+        assert set(weak) <= set(bad), (weak, bad)
         self.reruns += len(bad)
         segs = [(o, h, f | (ndist.SEG_SKIP if i in bad else 0)) for i, (o, h, f) in enumerate(segs)]
         sizes = np.zeros((max(n, 1), 3), dtype=np.uint64)

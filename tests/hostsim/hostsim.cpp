@@ -87,7 +87,14 @@ static const ntedit_hip_segment* g_x_segments = nullptr;
 static uint64_t* g_x_sizes = nullptr;
 static uint32_t* g_x_covers = nullptr;
 static unsigned g_x_flags = 0;
+static uint8_t* g_x_cuts_ok = nullptr; // per entry: nte_host::cuts_ok (= ntedit_hip_result_cuts_ok) for g_x_segments
 static std::string g_x_edits_path;
+
+extern "C" void
+hostsim_set_cuts_ok(uint8_t* ok)
+{
+	g_x_cuts_ok = ok;
+}
 
 extern "C" void
 hostsim_set_render_extras(const ntedit_hip_segment* segments, uint64_t* sizes, uint32_t* covers, unsigned flags, const char* edits_path)
@@ -298,6 +305,16 @@ hostsim_polish(
 			return -9;
 		}
 	}
+	if (g_x_cuts_ok && g_x_segments) {
+		std::vector<uint32_t> halos(n_contigs);
+		for (uint32_t i = 0; i < n_contigs; i++) {
+			halos[i] = g_x_segments[i].halo;
+		}
+		if (nte_host::cuts_ok(arena.data(), arena.size(), ev_first.data(), ev_first.size(), n_contigs, lens, halos.data(), g_x_cuts_ok)) {
+			return -9;
+		}
+	}
+	g_x_cuts_ok = nullptr;
 	if (g_x_sizes) {
 		memset(g_x_sizes, 0, (size_t)n_contigs * 3 * sizeof(uint64_t));
 	}

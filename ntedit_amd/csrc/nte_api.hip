@@ -441,6 +441,7 @@ struct WcPlan
 	u32 cap;
 	u64 n_wtiles;
 	u64 record_bytes;
+	bool short_runs; // the runs cannot hold what the pairs expect (WC_MAX_RUN): the chunk has to be smaller
 };
 
 WcPlan
@@ -467,6 +468,7 @@ plan_wc(const ntedit_hip_ctx* c, u64 kmers, u32 hash_num, u32 n_slices)
 		cap = mean * c->tune.bin_cap_percent / 100.0 + 8.0; // tests: force the overflow path
 	}
 	u64 capi = ((u64)cap + WC_GROUP - 1) / WC_GROUP * WC_GROUP;
+	w.short_runs = !c->tune.bin_cap_percent && capi > WC_MAX_RUN;
 	if (capi > WC_MAX_RUN) {
 		capi = WC_MAX_RUN; // (what does not fit goes through the overflow list)
 	}
@@ -535,7 +537,11 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
 			room = (u64)(free_b + c->bin_records[0].cap + c->bin_records[1].cap) / 5 * (overlap ? 1 : 2);
 		}
-		while (parts < 4096 && plan_wc(c, (span + parts - 1) / parts, f.hash_num, n_slices).record_bytes > room) {
+		for (;;) {
+			const WcPlan pl = plan_wc(c, (span + parts - 1) / parts, f.hash_num, n_slices);
+			if (parts >= 4096 || (pl.record_bytes <= room && !pl.short_runs)) {
+				break;
+			}
 			parts++;
 		}
 		if (plan_wc(c, (span + parts - 1) / parts, f.hash_num, n_slices).record_bytes > room) {

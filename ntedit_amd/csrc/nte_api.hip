@@ -110,6 +110,7 @@ struct ntedit_hip_ctx
 		u32 force_rounds = 0;     // event rounds whatever the number of events (tests: small inputs)
 		u32 probe_parts_log2 = 0; // the probe stage walks every slice 2^n times, one part of it per walk
 		u32 records_uncached = 0; // the screening records in memory the L2 does not keep (experiments)
+		u32 bin_scatter = 0;      // partition kernel: 0 barrier-phased (k_wc_scatter_b), 1 barrier-free (k_wc_scatter)
 		u32 bin_overlap = 0;      // partition chunk j + 1 while chunk j is probed (two record buffers, a second stream)
 	} tune;
 	DevBuf ev_cover, ev_before, ev_flags, ev_list, ev_bmax; // event rounds
@@ -482,10 +483,16 @@ int
 launch_wc(ntedit_hip_ctx* c, hipStream_t stream, const WcArgs& w)
 {
 	// (per device: the attribute belongs to the function ON the current device)
-	const size_t lds = wc_lds_bytes(w.b.p.k);
-	HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wc_scatter<H, POW2>),
-	                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL((k_wc_scatter<H, POW2>), dim3(w.n_wg), dim3(WC_TPB), lds, stream, w);
+	if (c->tune.bin_scatter == 1) {
+		const size_t lds = wc_lds_bytes(w.b.p.k);
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wc_scatter<H, POW2>),
+		                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		hipLaunchKernelGGL((k_wc_scatter<H, POW2>), dim3(w.n_wg), dim3(WC_TPB), lds, stream, w);
+	} else {
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wc_scatter_b<H, POW2>),
+		                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)WCB_LDS_BYTES));
+		hipLaunchKernelGGL((k_wc_scatter_b<H, POW2>), dim3(w.n_wg), dim3(WCB_TPB), WCB_LDS_BYTES, stream, w);
+	}
 	return 0;
 }
 
@@ -2507,6 +2514,8 @@ ntedit_hip_set_tuning(ntedit_hip_ctx* c, const char* key, uint64_t value)
 		t.no_lds_ws = (u32)value;
 	} else if (k == "probe_parts_log2") {
 		t.probe_parts_log2 = (u32)value < 4 ? (u32)value : 3;
+	} else if (k == "bin_scatter") {
+		t.bin_scatter = (u32)value;
 	} else if (k == "bin_overlap") {
 		t.bin_overlap = (u32)value;
 	} else if (k == "records_uncached") {

@@ -49,6 +49,9 @@ def child(idx):
     pol.set_tuning("bin_timing", 1)
     for k_, v in tune.items():
         pol.set_tuning(k_, v)
+    for kv in filter(None, os.environ.get("SCREEN_CHECK_TUNE", "").split(",")):  # (extra knobs for every case)
+        k_, _, v = kv.partition("=")
+        pol.set_tuning(k_, int(v))
     t0 = time.time()
     got = pol.screen(blob)
     dt = time.time() - t0

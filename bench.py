@@ -541,7 +541,7 @@ def main():
                 "launches_per_step": launches[0],
                 "probes_per_s": round(args.hashes * my_bytes / (step_screen * 1e-3), 0),
                 "pipeline": {
-                    "kernels": ["k_wc_scatter", "k_bin_probe", "k_ovf_probe"] if binned else ["k_screen"],
+                    "kernels": ["k_wc_scatter_b", "k_bin_probe", "k_ovf_probe"] if binned else ["k_screen"],
                     "ms_per_step": round(step_screen, 3),
                     "algorithmic_bytes_per_step": int((args.hashes + 1 + 0.125) * my_bytes),
                     "achieved": round((args.hashes + 1 + 0.125) * my_bytes / (step_screen * 1e-3) / 1e9, 2),

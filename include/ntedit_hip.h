@@ -178,7 +178,7 @@ typedef struct ntedit_hip_stats
 	float ms_total;          /* first kernel start -> edit records in host memory */
 	uint32_t screen_launches; /* launches of the dominant screening kernel in this batch: k_bin_probe (binned
 	                             screening, one per record chunk) or k_screen (direct; pipeline chunks / H2D pieces) */
-	uint32_t screen_binned;   /* 1: binned pipeline (k_wc_scatter, k_bin_probe), 0: k_screen */
+	uint32_t screen_binned;   /* 1: binned pipeline (k_wc_scatter_b, k_bin_probe), 0: k_screen */
 	float ms_partition;       /* binned: HIP-event time of the partition kernels (count + scan + scatter), sum */
 	float ms_probe;           /* binned: HIP-event time of the k_bin_probe launches, sum */
 	uint32_t events_skipped;  /* events not run because they start inside their cluster primary's run */
@@ -350,7 +350,7 @@ void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
  * implementations that are bit-identical by construction (and tested to be), split work differently, or print
  * timings.  Keys: "screen_mode" (overrides params.screen_mode), "bin_chunk" (k-mer starts per record chunk of the
  * partitioned screening), "bin_cap_percent" (record-run capacity in percent of the expectation: forces the overflow
- * list), "bin_fallback" (1: direct kernel from now on, as after a lost overflow), "bin_overlap" (partition a record chunk while the previous one is probed), "probe_parts_log2",
+ * list), "bin_fallback" (1: direct kernel from now on, as after a lost overflow), "bin_scatter" (1: the barrier-free partition kernel), "bin_overlap" (partition a record chunk while the previous one is probed), "probe_parts_log2",
  * "force_xcc" (x + 1: the probe
  * stage behaves as if every wavefront ran on XCD x), "bin_timing", "chunk_bytes" (pipeline chunk size), "h2d_piece"
  * (bytes per host-to-device piece), "inline_tries", "screen_lds_pad", "no_rounds", "force_rounds", "no_early_copy", "no_lds_ws".

@@ -469,9 +469,10 @@ plan_wc(const ntedit_hip_ctx* c, u64 kmers, u32 hash_num, u32 n_slices)
 		cap = mean * c->tune.bin_cap_percent / 100.0 + 8.0; // tests: force the overflow path
 	}
 	u64 capi = ((u64)cap + WC_GROUP - 1) / WC_GROUP * WC_GROUP;
-	w.short_runs = !c->tune.bin_cap_percent && capi > WC_MAX_RUN;
-	if (capi > WC_MAX_RUN) {
-		capi = WC_MAX_RUN; // (what does not fit goes through the overflow list)
+	const u64 max_run = WC_MAX_RUN;
+	w.short_runs = !c->tune.bin_cap_percent && capi > max_run;
+	if (capi > max_run) {
+		capi = max_run; // (what does not fit goes through the overflow list)
 	}
 	w.cap = (u32)capi;
 	w.record_bytes = (u64)n_slices * w.n_wg * w.cap * 8;

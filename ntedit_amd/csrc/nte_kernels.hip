@@ -241,13 +241,12 @@ k_screen(
 // 64-byte fabric request (~51 G requests/s measured, the same as a pure random-gather micro-benchmark),
 // while gathers that HIT in an XCD's 4 MiB L2 run at up to ~270 G/s.  The binned pipeline makes the probes
 // L2-resident by partitioning them by filter slice first:
-//   k_wc_count / k_wc_scan / k_wc_scatter   (nte_bin_wc.inc) write-combining partition of the h probes of
-//                  every k-mer into {position, offset-in-slice} records, slice by slice
-//   k_bin_probe    every XCD walks "its" slices (slice % 8 == XCD) one after the other: the slice's 2-4 MiB
-//                  of filter stay in that XCD's L2 while its records stream by; a zero bit ORs the k-mer's
-//                  bit into the absent bitmap
-// Records are 8 bytes: (global k-mer position << slice_log2) | bit offset in slice.
-// Measured (MI355X, 3 Gbp, 4 GiB filter, h = 3): 116-121 ms against 176 ms for the direct kernel.
+//   k_wc_scatter_b (default) / k_wc_scatter   (nte_bin_wc.inc) write-combining partition of the h probes of every
+//                  k-mer into {position, offset-in-slice} records, slice by slice, ONE pass over the draft
+//   k_bin_probe    every XCD walks slices one after the other: the slice's 2-4 MiB of filter stay in that XCD's L2
+//                  while its records stream by; a zero bit ORs the k-mer's bit into the absent bitmap
+// Records are 8 bytes: (global k-mer position << slice_log2) | slot offset in slice.
+// Measured (MI355X, 3 Gbp, 4 GiB filter, h = 3): 94 ms against 176 ms for the direct kernel.
 constexpr u64 WC_EMPTY_REC = ~0ULL;             // padding of a run's last 64-byte group: no record
 constexpr u64 WC_REC_POS_MASK = ~(1ULL << 63);  // bit 63 of a stored record is the ring generation bit
 

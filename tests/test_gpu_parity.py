@@ -164,6 +164,10 @@ def test_binned_screen_matches_oracle(tmp_path, ci, oracle_build):
         got = pol.screen(blob)
         pol.set_tuning("bin_chunk", 0)
         one_chunk = pol.screen(blob)
+        pol.set_tuning("bin_scatter", 1)  # (the barrier-free partition kernel)
+        free_one = pol.screen(blob)
+        pol.set_tuning("bin_chunk", 3 * 16384)
+        free_chunks = pol.screen(blob)
         pol.set_params(ntedit_amd.default_params(screen_mode=1))
         direct = pol.screen(blob)
     finally:
@@ -171,6 +175,8 @@ def test_binned_screen_matches_oracle(tmp_path, ci, oracle_build):
     assert np.array_equal(direct, want)
     assert np.array_equal(got, want)
     assert np.array_equal(one_chunk, want)
+    assert np.array_equal(free_one, want)
+    assert np.array_equal(free_chunks, want)
 
 
 @pytest.mark.parametrize("xcc", [0, 3, 7, 12])
@@ -194,8 +200,9 @@ def test_binned_probe_on_any_xcd_count(tmp_path, xcc, oracle_build):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("scatter", [0, 1])
 @pytest.mark.parametrize("percent", [50, 5])
-def test_binned_overflow_list(tmp_path, percent, oracle_build):
+def test_binned_overflow_list(tmp_path, percent, scatter, oracle_build):
     """record runs sized far below what the pairs get: the excess goes through the overflow list (direct probes);
     same bitmap.  A low-complexity draft does this in the field."""
     import ntedit_amd
@@ -208,6 +215,7 @@ def test_binned_overflow_list(tmp_path, percent, oracle_build):
         pol.set_filter(bf["data"], bf["hash_num"], bf["k"])
         pol.set_params(ntedit_amd.default_params(screen_mode=2))
         pol.set_tuning("bin_cap_percent", percent)
+        pol.set_tuning("bin_scatter", scatter)
         got = pol.screen(blob)
     finally:
         pol.close()
@@ -233,9 +241,12 @@ def test_binned_homopolymer_draft(tmp_path, oracle_build):
         pol.set_filter(bf["data"], bf["hash_num"], bf["k"])
         pol.set_params(ntedit_amd.default_params(screen_mode=2))
         got = pol.screen(blob)
+        pol.set_tuning("bin_scatter", 1)
+        got_free = pol.screen(blob)
     finally:
         pol.close()
     assert np.array_equal(got, want)
+    assert np.array_equal(got_free, want)
 
 
 @pytest.mark.parametrize("ci", [0, 8, 10, 23])

@@ -128,6 +128,8 @@ def main():
                         cmd += ["--tune", "bin_cap_percent=%d" % int(rng.choice([10, 60, 90]))]
                     if rng.random() < 0.3:
                         cmd += ["--tune", "force_xcc=%d" % int(rng.integers(1, 17))]
+                    if rng.random() < 0.4:
+                        cmd += ["--tune", "bin_scatter=1"]
                 if rng.random() < 0.5:
                     cmd += ["--tune", "force_rounds=1"]  # (the event rounds, which small batches do not use by themselves)
                 if "start_grid" in par_kw:

@@ -469,7 +469,7 @@ plan_wc(const ntedit_hip_ctx* c, u64 kmers, u32 hash_num, u32 n_slices)
 		cap = mean * c->tune.bin_cap_percent / 100.0 + 8.0; // tests: force the overflow path
 	}
 	u64 capi = ((u64)cap + WC_GROUP - 1) / WC_GROUP * WC_GROUP;
-	const u64 max_run = WC_MAX_RUN;
+	const u64 max_run = c->tune.bin_scatter == 1 ? WC_MAX_RUN : WCB_MAX_RUN;
 	w.short_runs = !c->tune.bin_cap_percent && capi > max_run;
 	if (capi > max_run) {
 		capi = max_run; // (what does not fit goes through the overflow list)

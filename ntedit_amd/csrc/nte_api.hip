@@ -534,11 +534,7 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 	const u64 unit = (u64)WC_WTILE * WC_WAVES; // chunk sizes: whole workgroup rounds (also a multiple of 16 bytes)
 	const bool overlap = c->tune.bin_overlap && span >= (1ULL << 28);
 	u64 parts = overlap ? 4 : 1;
-	if (c->h2d_piece_bytes && span >= (1ULL << 28)) {
-		// the batch is still crossing PCIe: in several record chunks the screening of the bases that have arrived runs
-		// under the copy of the rest (every chunk waits for its own pieces only)
-		parts = span >> 28 < 6 ? span >> 28 : 6;
-	}
+	const bool arriving = c->h2d_piece_bytes && span >= 4 * c->h2d_piece_bytes && !overlap;
 	{
 		size_t free_b = 0, total_b = 0;
 		u64 room = ~0ULL;
@@ -592,7 +588,29 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		const u64 w0 = pos_begin / 64, w1 = (pos_end + 63) / 64 < n_words ? (pos_end + 63) / 64 : n_words;
 		HIP_TRY(c, hipMemsetAsync(d_bitmap + w0, 0, (w1 - w0) * 8, stream));
 	}
-	const u64 n_chunks = (span + chunk - 1) / chunk;
+	// chunk boundaries.  A batch that is still crossing PCIe is screened in chunks that grow -- one copy piece, three,
+	// eight, the rest: every chunk waits for its own pieces only, the first one for 128 MB instead of the whole batch,
+	// and the copy (55 GB/s) stays ahead of the screening (32 GB/s) from there on.
+	std::vector<u64> cuts;
+	{
+		u64 at = pos_begin, step = chunk;
+		if (arriving) {
+			step = c->h2d_piece_bytes / unit * unit;
+			step = step < unit ? unit : step;
+		}
+		while (at < pos_end) {
+			u64 len = step < chunk ? step : chunk;
+			if (arriving && pos_end - at < len + len / 2) {
+				len = pos_end - at < chunk ? pos_end - at : chunk; // (no small rest)
+			}
+			at = at + len < pos_end ? at + len : pos_end;
+			cuts.push_back(at);
+			if (arriving) {
+				step = step * 3 < chunk ? step * 3 : chunk;
+			}
+		}
+	}
+	const u64 n_chunks = cuts.size();
 	// per chunk: [0] partition begins, [1] partitioned, [2] probe begins, [3] probed (timed; [1] and [3] also order the streams)
 	while (c->bin_ev.size() < 4 * (size_t)n_chunks) {
 		hipEvent_t e;
@@ -600,8 +618,8 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 		c->bin_ev.push_back(e);
 	}
 	u32 chunk_no = 0;
-	for (u64 begin = pos_begin; begin < pos_end; begin += chunk, chunk_no++) {
-		const u64 end = begin + chunk < pos_end ? begin + chunk : pos_end;
+	for (u64 begin = pos_begin; chunk_no < n_chunks; begin = cuts[chunk_no], chunk_no++) {
+		const u64 end = cuts[chunk_no];
 		const WcPlan plan = plan_wc(c, end - begin, f.hash_num, n_slices);
 		const int q = two ? (int)(chunk_no & 1) : 0;
 		u32* d_ctl = (u32*)c->bin_ctl[q].p;

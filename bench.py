@@ -215,6 +215,8 @@ def measured_regions(job, pol, args):
         out["end_to_end"] = {
             "value": round(rep["bases"] / sec / 1e6, 2), "unit": "Mbases/s", "region_s": round(sec, 4),
             "region_s_all_runs": [round(x[0], 4) for x in runs],
+            "stage_s_all_runs": [{"fasta_parse": x[2]["read_s"], "polish_batch_calls": x[2]["polish_call_s"],
+                                  "apply_render_write": x[2]["write_s"], "gpu_ms": x[2]["gpu_ms"]} for x in runs],
             "median_value": round(rep["bases"] / all_s[len(all_s) // 2] / 1e6, 2),
             "process_wall_s": round(wall, 3),
             "stage_s": {"open_outputs": rep.get("open_outputs_s"), "fasta_index": rep.get("index_s"),

@@ -93,3 +93,20 @@ def test_cli_argument_errors(built_lib, tmp_path):
     assert r.returncode != 0 and "invalid option" in r.stderr  # ntedit.cpp:2360-2363
     r = subprocess.run([cli, "--help"], capture_output=True, text=True)
     assert r.returncode == 0 and "-f," in r.stderr
+
+
+def test_library_reads_two_environment_variables_only():
+    """no result-altering or tuning hook may hide behind an environment variable in the shipped
+    library -- knobs go through ntedit_hip_set_tuning(), the timing-ablation switches live in `make ablation`."""
+    import re
+    from ntedit_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    names = sorted(set(m.decode() for m in re.findall(rb"NTEDIT_HIP_[A-Z0-9_]+", blob)))
+    assert names == ["NTEDIT_HIP_DEBUG", "NTEDIT_HIP_NO_BIND"], names
+
+
+def test_set_tuning_rejects_unknown_keys_without_a_device():
+    """(no GPU needed: a null context is an argument error, not a crash)"""
+    from ntedit_amd import _lib
+    lib = _lib.load()
+    assert lib.ntedit_hip_set_tuning(None, b"screen_mode", 1) != 0

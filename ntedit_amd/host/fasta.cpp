@@ -1,17 +1,36 @@
 #include "fasta.h"
+#include "gunzip.h"
 
+#include <atomic>
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
+#include <sys/stat.h>
 
 namespace nte_host {
+
+static std::atomic<int> g_gzip_through_zlib{ 0 };
+
+int
+set_gzip_through_zlib(int on)
+{
+	return g_gzip_through_zlib.exchange(on ? 1 : 0);
+}
 
 // large reads go straight from the file into the block when the input is not compressed
 // (zlib copies directly once a request is at least twice its own buffer)
 static const int BUFSZ = 4 << 20;
 
+// (every block has room for the decoder's window in front of it and for an overrunning match behind it)
+unsigned char*
+FastaReader::data_(int s) const
+{
+	return slot_[s] + Gunzip::WINDOW;
+}
+
 FastaReader::FastaReader(const char* path)
-  : f_(gzopen(path, "r"))
+  : f_(nullptr)
+  , gz_(nullptr)
   , buf_(nullptr)
   , begin_(0)
   , end_(0)
@@ -21,19 +40,38 @@ FastaReader::FastaReader(const char* path)
   , failed_(false)
   , head_(0)
   , tail_(0)
+  , crc_done_(0)
   , cur_(-1)
   , stop_(false)
 {
 	for (int i = 0; i < NSLOTS; i++) {
 		slot_[i] = nullptr;
 		slot_len_[i] = 0;
+		slot_eof_[i] = slot_member_end_[i] = false;
+		slot_crc_[i] = slot_isize_[i] = 0;
 	}
-	if (f_) {
-		gzbuffer(f_, 1 << 17);
+	struct stat st;
+	if (!g_gzip_through_zlib.load() && stat(path, &st) == 0 && S_ISREG(st.st_mode)) {
+		gz_ = new Gunzip();
+		if (!gz_->open(path)) {
+			delete gz_; // not a gzip stream (or not readable: gzopen says so below)
+			gz_ = nullptr;
+		}
+	}
+	if (!gz_) {
+		f_ = gzopen(path, "r");
+	}
+	if (f_ || gz_) {
+		if (f_) {
+			gzbuffer(f_, 1 << 17);
+		}
 		for (int i = 0; i < NSLOTS; i++) {
-			slot_[i] = (unsigned char*)malloc(BUFSZ);
+			slot_[i] = (unsigned char*)malloc(Gunzip::WINDOW + BUFSZ + Gunzip::SLACK);
 		}
 		io_ = std::thread([this]() { io_loop_(); });
+		if (gz_) {
+			crc_ = std::thread([this]() { crc_loop_(); });
+		}
 	}
 }
 
@@ -46,10 +84,14 @@ FastaReader::~FastaReader()
 		}
 		cv_.notify_all();
 		io_.join();
+		if (crc_.joinable()) {
+			crc_.join();
+		}
 	}
 	if (f_) {
 		gzclose(f_);
 	}
+	delete gz_;
 	for (int i = 0; i < NSLOTS; i++) {
 		free(slot_[i]);
 	}
@@ -63,28 +105,44 @@ FastaReader::io_loop_()
 		int s;
 		{
 			std::unique_lock<std::mutex> lk(mu_);
-			cv_.wait(lk, [&]() { return stop_ || head_ - tail_ < NSLOTS; });
+			cv_.wait(lk, [&]() { return stop_ || (head_ - tail_ < NSLOTS && (!gz_ || head_ - crc_done_ < NSLOTS)); });
 			if (stop_) {
 				return;
 			}
 			s = (int)(head_ % NSLOTS);
 		}
-		int n = gzread(f_, slot_[s], BUFSZ);
-		bool bad = n < 0;
+		int n;
+		bool bad = false, member_end = false;
+		unsigned crc = 0, isize = 0;
 		std::string why;
-		if (n < BUFSZ) {
-			// a short or failed read: end of file, or a stream that broke (zlib reports a truncated
-			// .gz as Z_BUF_ERROR and corrupt data as Z_DATA_ERROR only through gzerror)
-			int errnum = Z_OK;
-			const char* msg = gzerror(f_, &errnum);
-			if (errnum != Z_OK && errnum != Z_STREAM_END) {
+		if (gz_) {
+			n = (int)gz_->read(data_(s), BUFSZ);
+			member_end = gz_->member_end();
+			crc = gz_->member_crc();
+			isize = gz_->member_isize();
+			if (gz_->failed()) {
 				bad = true;
-				why = msg ? msg : "read error";
+				why = gz_->error();
+				n = 0;
+			}
+		} else {
+			n = gzread(f_, data_(s), BUFSZ);
+			bad = n < 0;
+			if (n < BUFSZ) {
+				// a short or failed read: end of file, or a stream that broke (zlib reports a truncated
+				// .gz as Z_BUF_ERROR and corrupt data as Z_DATA_ERROR only through gzerror)
+				int errnum = Z_OK;
+				const char* msg = gzerror(f_, &errnum);
+				if (errnum != Z_OK && errnum != Z_STREAM_END) {
+					bad = true;
+					why = msg ? msg : "read error";
+				}
+			}
+			if (n < 0) {
+				n = 0;
 			}
 		}
-		if (n < 0) {
-			n = 0;
-		}
+		const bool eof = n == 0 && !member_end;
 		{
 			std::lock_guard<std::mutex> lk(mu_);
 			if (bad) {
@@ -92,11 +150,68 @@ FastaReader::io_loop_()
 				io_error_text_ = why.empty() ? "read error" : why;
 			}
 			slot_len_[s] = n;
+			slot_eof_[s] = eof;
+			slot_member_end_[s] = member_end;
+			slot_crc_[s] = crc;
+			slot_isize_[s] = isize;
 			head_++;
 		}
 		cv_.notify_all();
-		if (n == 0) {
+		if (eof) {
 			return; // end of file (an empty block marks it)
+		}
+	}
+}
+
+// checksum thread (our own decoder only): CRC-32 and length of every gzip member against its trailer, block by
+// block behind the I/O thread -- at the decoder's speed the checksum would otherwise take a third of its time
+void
+FastaReader::crc_loop_()
+{
+	unsigned long running = crc32(0L, Z_NULL, 0);
+	unsigned long long total = 0;
+	for (;;) {
+		int s, n;
+		bool eof, member_end;
+		unsigned crc, isize;
+		{
+			std::unique_lock<std::mutex> lk(mu_);
+			cv_.wait(lk, [&]() { return stop_ || crc_done_ < head_; });
+			if (stop_) {
+				return;
+			}
+			s = (int)(crc_done_ % NSLOTS);
+			n = slot_len_[s];
+			eof = slot_eof_[s];
+			member_end = slot_member_end_[s];
+			crc = slot_crc_[s];
+			isize = slot_isize_[s];
+		}
+		const char* why = nullptr;
+		if (!eof) {
+			running = crc32(running, data_(s), (unsigned)n);
+			total += (unsigned long long)n;
+			if (member_end) {
+				if ((unsigned)running != crc) {
+					why = "incorrect data check";
+				} else if ((unsigned)(total & 0xffffffffull) != isize) {
+					why = "incorrect length check";
+				}
+				running = crc32(0L, Z_NULL, 0);
+				total = 0;
+			}
+		}
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			if (why && !io_error_) {
+				io_error_ = true;
+				io_error_text_ = why;
+			}
+			crc_done_++;
+		}
+		cv_.notify_all();
+		if (eof) {
+			return;
 		}
 	}
 }
@@ -108,22 +223,30 @@ FastaReader::fill_()
 		return false;
 	}
 	std::unique_lock<std::mutex> lk(mu_);
-	if (cur_ >= 0) {
-		tail_++; // the block the parser has finished with goes back to the I/O thread
-		cur_ = -1;
-		cv_.notify_all();
+	for (;;) {
+		if (cur_ >= 0) {
+			tail_++; // the block the parser has finished with goes back to the I/O thread
+			cur_ = -1;
+			cv_.notify_all();
+		}
+		cv_.wait(lk, [&]() { return head_ > tail_; });
+		const int s = (int)(tail_ % NSLOTS);
+		if (slot_eof_[s]) {
+			// (what io_error() says must be final when next() reports the end: wait for the last checksum)
+			cv_.wait(lk, [&]() { return !gz_ || crc_done_ >= head_; });
+			eof_ = true;
+			begin_ = end_ = 0;
+			return false;
+		}
+		cur_ = s;
+		if (slot_len_[s] > 0) {
+			break;
+		}
+		// (an empty block that is not the last one: a gzip member without data)
 	}
-	cv_.wait(lk, [&]() { return head_ > tail_; });
-	const int s = (int)(tail_ % NSLOTS);
-	if (slot_len_[s] <= 0) {
-		eof_ = true;
-		begin_ = end_ = 0;
-		return false;
-	}
-	cur_ = s;
-	buf_ = slot_[s];
+	buf_ = data_(cur_);
 	begin_ = 0;
-	end_ = slot_len_[s];
+	end_ = slot_len_[cur_];
 	return true;
 }
 
@@ -170,7 +293,7 @@ bool
 FastaReader::next(std::string& header, std::string& seq)
 {
 	int c;
-	if (failed_ || !f_) {
+	if (failed_ || !ok()) {
 		return false;
 	}
 	if (last_char_ == 0) {

@@ -411,6 +411,71 @@ hostsim_fasta_dump(const char* in_path, const char* out_path)
 	return n;
 }
 
+// TEST-ONLY: reads a file to its end with the streaming reader; 1 if it reported a damaged input (io_error), 0 if not, -1 cannot open
+extern "C" int
+hostsim_fasta_io_error(const char* in_path)
+{
+	nte_host::FastaReader r(in_path);
+	if (!r.ok()) {
+		return -1;
+	}
+	std::string hdr, blob;
+	while (r.next(hdr, blob)) {
+		blob.clear();
+	}
+	return r.io_error() ? 1 : 0;
+}
+
+// TEST-ONLY: 1 = the streaming reader inflates through zlib instead of host/gunzip.cpp; returns the old setting
+extern "C" int
+hostsim_gzip_through_zlib(int on)
+{
+	return nte_host::set_gzip_through_zlib(on);
+}
+
+// TEST-ONLY: inflates a .gz file with host/gunzip.cpp alone into out_path, `block` bytes per read() call (so that tests
+// can put the block boundaries anywhere).  Returns the bytes written; -1 not a gzip file, -2 output, -3 the stream
+// failed (what it produced up to there is in the file), -4 a member's CRC-32 or length does not match its trailer
+#include "../../ntedit_amd/host/gunzip.h"
+#include <zlib.h>
+extern "C" long long
+hostsim_gunzip(const char* in_path, const char* out_path, unsigned block)
+{
+	nte_host::Gunzip g;
+	if (!g.open(in_path)) {
+		return -1;
+	}
+	FILE* o = fopen(out_path, "wb");
+	if (!o) {
+		return -2;
+	}
+	std::vector<unsigned char> buf(nte_host::Gunzip::WINDOW + (size_t)block + nte_host::Gunzip::SLACK);
+	unsigned char* dst = buf.data() + nte_host::Gunzip::WINDOW;
+	long long total = 0;
+	unsigned long crc = crc32(0L, Z_NULL, 0);
+	unsigned long long member = 0;
+	bool mismatch = false;
+	for (;;) {
+		const size_t n = g.read(dst, block);
+		if (n == 0 && !g.member_end()) {
+			break;
+		}
+		fwrite(dst, 1, n, o);
+		total += (long long)n;
+		crc = crc32(crc, dst, (unsigned)n);
+		member += n;
+		if (g.member_end()) {
+			if ((unsigned)crc != g.member_crc() || (unsigned)(member & 0xffffffffull) != g.member_isize()) {
+				mismatch = true;
+			}
+			crc = crc32(0L, Z_NULL, 0);
+			member = 0;
+		}
+	}
+	fclose(o);
+	return g.failed() ? -3 : mismatch ? -4 : total;
+}
+
 // TEST-ONLY: the same dump through the mapped, multi-threaded reader (ntedit_amd/host/fasta_map.cpp);
 // -1 when it refuses the file (then the streaming reader is the one that parses it)
 #include "../../ntedit_amd/host/fasta_map.h"

@@ -1,0 +1,212 @@
+"""The host's own gzip decoder (ntedit_amd/host/gunzip.cpp) against zlib: it stands where the reference has zlib's
+gzread under kseq (lib/kseq.h:44-50, KSEQ_INIT(gzFile, gzread) at ntedit.cpp:25), so whatever gzread returns for a
+file -- the bytes, or a failure -- is what it must return."""
+import ctypes
+import gzip
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def gunzip(path, tmp_path, block=1 << 16):
+    lib = H.hostsim_lib()
+    lib.hostsim_gunzip.restype = ctypes.c_longlong
+    out = str(tmp_path / "out.bin")
+    rc = lib.hostsim_gunzip(ctypes.c_char_p(path.encode()), ctypes.c_char_p(out.encode()), ctypes.c_uint(block))
+    data = b""
+    if rc != -1 and rc != -2:
+        with open(out, "rb") as f:
+            data = f.read()
+    return rc, data
+
+
+def deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=31, memlevel=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, memlevel, strategy)
+    return c.compress(data) + c.flush()
+
+
+def dna(rng, n, width=60, repeats=True):
+    a = rng.integers(0, 4, n, dtype=np.uint8)
+    if repeats and n > 4000:
+        pos = 2000
+        while pos < n - 3000:
+            L = int(rng.integers(20, 2000))
+            src = int(rng.integers(0, pos - L)) if pos > L else 0
+            a[pos:pos + L] = a[src:src + L]
+            pos += int(rng.integers(500, 20000))
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[a].tobytes()
+    return b">c1 a draft\n" + b"\n".join(s[i:i + width] for i in range(0, n, width)) + b"\n"
+
+
+def payloads():
+    rng = np.random.default_rng(7)
+    text = (b"the quick brown fox jumps over the lazy dog; " * 3000) + bytes(rng.integers(32, 127, 20000, dtype=np.uint8))
+    return {
+        "empty": b"",
+        "one": b"A",
+        "dna_small": dna(rng, 5000),
+        "dna": dna(rng, 3_000_000),
+        "dna_norepeat": dna(rng, 400_000, repeats=False),
+        "text": text,
+        "random": bytes(rng.integers(0, 256, 300_000, dtype=np.uint8)),  # incompressible: stored blocks at any level
+        "zeros": bytes(2_000_000),  # distance-1 matches of the maximum length
+        "period3": b"ACG" * 500_000,  # overlapping matches with a distance below eight
+        "skewed": bytes(rng.choice(np.arange(256, dtype=np.uint8), 500_000,
+                                   p=np.array([2.0 ** -(1 + i // 4) for i in range(256)]) / sum(2.0 ** -(1 + i // 4) for i in range(256)))),
+    }
+
+
+PAYLOADS = payloads()
+ENCODINGS = [
+    ("stored", dict(level=0)),
+    ("fast", dict(level=1)),
+    ("default", dict(level=6)),
+    ("best", dict(level=9)),
+    ("fixed", dict(level=6, strategy=zlib.Z_FIXED)),
+    ("huffman_only", dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY)),
+    ("rle", dict(level=6, strategy=zlib.Z_RLE)),
+    ("small_blocks", dict(level=6, memlevel=1)),  # a new dynamic block every 256 symbols
+    ("small_window", dict(level=6, wbits=16 + 9)),
+]
+
+
+@pytest.mark.parametrize("enc", [e[0] for e in ENCODINGS])
+@pytest.mark.parametrize("name", list(PAYLOADS))
+def test_gunzip_equals_zlib(tmp_path, name, enc):
+    data = PAYLOADS[name]
+    z = deflate(data, **dict(ENCODINGS)[enc])
+    assert zlib.decompress(z, 31) == data
+    p = str(tmp_path / "in.gz")
+    with open(p, "wb") as f:
+        f.write(z)
+    for block in ((1 << 22), 65536, 4099) if len(data) > 100000 else ((1 << 22), 4099, 100, 7, 1):
+        rc, got = gunzip(p, tmp_path, block)
+        assert rc == len(data), (name, enc, block, rc)
+        assert got == data, (name, enc, block)
+
+
+def gz_header(flags=0, extra=b"", name=b"", comment=b"", hcrc=False):
+    h = bytearray(b"\x1f\x8b\x08" + bytes([flags]) + b"\0\0\0\0\0\x03")
+    if flags & 4:
+        h += struct.pack("<H", len(extra)) + extra
+    if flags & 8:
+        h += name + b"\0"
+    if flags & 16:
+        h += comment + b"\0"
+    if flags & 2:
+        h += struct.pack("<H", zlib.crc32(bytes(h)) & 0xffff)
+    return bytes(h)
+
+
+def member(data, flags=0, level=6, **kw):
+    raw = deflate(data, level=level, wbits=-15)
+    return gz_header(flags, **kw) + raw + struct.pack("<II", zlib.crc32(data), len(data) & 0xffffffff)
+
+
+def test_gunzip_header_fields_and_members(tmp_path):
+    rng = np.random.default_rng(3)
+    a, b, c = dna(rng, 70000), b"", dna(rng, 300)
+    p = str(tmp_path / "in.gz")
+    blob = (member(a, 4 | 8 | 16 | 2, extra=b"BC\x02\x00\x12\x34" * 50, name=b"draft.fa", comment=b"made by a test") + member(b) +
+            member(c, 8, name=b"x" * 5000) + member(a, 1))
+    assert gzip.decompress(blob) == a + b + c + a
+    for tail in (b"", b"\0" * 700, b"trailing text that is no gzip member", b"\x1f"):
+        with open(p, "wb") as f:
+            f.write(blob + tail)
+        for block in (1 << 20, 1000):
+            rc, got = gunzip(p, tmp_path, block)
+            assert rc == len(got) and got == a + b + c + a, (tail[:8], block, rc)
+    # the second member starts, and the file ends inside its header / its data / its trailer
+    full = member(a) + member(c)
+    for cut in (len(member(a)) + 2, len(member(a)) + 9, len(full) - 9, len(full) - 8, len(full) - 1):
+        with open(p, "wb") as f:
+            f.write(full[:cut])
+        with pytest.raises(Exception):
+            gzip.decompress(full[:cut])
+        rc, got = gunzip(p, tmp_path)
+        assert rc == -3, cut
+    # not gzip at all
+    with open(p, "wb") as f:
+        f.write(b">plain\nACGT\n")
+    assert gunzip(p, tmp_path)[0] == -1
+    with open(p, "wb") as f:
+        f.write(b"")
+    assert gunzip(p, tmp_path)[0] == -1
+
+
+def test_gunzip_damaged_streams(tmp_path):
+    """a damaged stream must never come back as a good one: it fails, or a member's checksum tells; where zlib still
+    inflates it (a flipped bit in a header field nobody reads) the bytes are zlib's"""
+    rng = np.random.default_rng(9)
+    data = dna(rng, 60000) + b">c2\n" + bytes(rng.integers(65, 91, 3000, dtype=np.uint8)) + b"\n"
+    p = str(tmp_path / "in.gz")
+    for enc in ("default", "fixed", "stored", "small_blocks"):
+        z = bytearray(deflate(data, **dict(ENCODINGS)[enc]))
+        # truncations
+        for cut in sorted(set(int(x) for x in rng.integers(1, len(z), 60)) | {1, 2, 9, 10, 11, len(z) - 1, len(z) - 8, len(z) - 9}):
+            with open(p, "wb") as f:
+                f.write(z[:cut])
+            rc, got = gunzip(p, tmp_path, 5000)
+            assert rc in (-1, -3), (enc, cut, rc)
+            assert data.startswith(got)
+        # flipped bits
+        for it in range(150):
+            y = bytearray(z)
+            pos = int(rng.integers(0, len(y)))
+            y[pos] ^= 1 << int(rng.integers(0, 8))
+            with open(p, "wb") as f:
+                f.write(y)
+            try:
+                want = gzip.decompress(bytes(y))
+            except Exception:
+                want = None
+            rc, got = gunzip(p, tmp_path, 5000)
+            if want is None:
+                assert rc < 0, (enc, pos, rc)
+            else:
+                assert rc == len(want) and got == want, (enc, pos, rc)
+
+
+def test_reader_backends_agree(tmp_path):
+    """the streaming FASTA reader gives the same records, and the same verdict on damaged files, whichever inflater runs"""
+    lib = H.hostsim_lib()
+    from test_fasta_reader import dump, model
+    rng = np.random.default_rng(21)
+    parts = []
+    for i in range(30):
+        n = int(rng.integers(1, 600000))
+        s = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), n))
+        w = int(rng.integers(20, 200))
+        parts.append(b">c%d len=%d\n" % (i, n) + b"\n".join(s[j:j + w] for j in range(0, n, w)) + b"\n")
+    data = b"".join(parts)
+    want = model(data)
+    p = str(tmp_path / "in.fa.gz")
+    variants = [deflate(data, 6), deflate(data, 1), deflate(data[:1 << 20], 6) + deflate(data[1 << 20:], 9), deflate(data, 0)]
+    try:
+        for z in variants:
+            with open(p, "wb") as f:
+                f.write(z)
+            for backend in (0, 1):
+                lib.hostsim_gzip_through_zlib(backend)
+                assert dump(p, tmp_path) == want
+                assert lib.hostsim_fasta_io_error(ctypes.c_char_p(p.encode())) == 0
+        z = bytearray(variants[0])
+        bad_crc = bytearray(z)
+        bad_crc[-6] ^= 0x40
+        bad_len = bytearray(z)
+        bad_len[-2] ^= 0x01
+        middle = bytearray(z)
+        middle[len(z) // 2] ^= 0x10
+        for broken in (z[:len(z) // 2], z[:-3], bad_crc, bad_len, middle):
+            with open(p, "wb") as f:
+                f.write(broken)
+            for backend in (0, 1):
+                lib.hostsim_gzip_through_zlib(backend)
+                assert lib.hostsim_fasta_io_error(ctypes.c_char_p(p.encode())) == 1, backend
+    finally:
+        lib.hostsim_gzip_through_zlib(0)

@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--screen-mode", type=int, default=0, help="0 auto, 1 direct gather, 2 L2-partitioned")
     ap.add_argument("--contig-len", type=int, default=0, help="contigs of exactly this many bases (configs[2]: 100000)")
     ap.add_argument("--no-weak", action="store_true", help="skip the weak-scaling leg at N>1")
+    ap.add_argument("--e2e-gzip", action="store_true", help="also run the end-to-end region on the draft as ONE gzip stream (level 6), "
+                    "inflated by host/gunzip.cpp and, for comparison, by zlib")
     ap.add_argument("--e2e-bgzf", action="store_true", help="also run the end-to-end region on a BGZF-compressed draft")
     ap.add_argument("--no-regions", action="store_true", help="skip the host-buffer and end-to-end regions (N=1)")
     ap.add_argument("--snv", action="store_true",
@@ -229,6 +231,32 @@ def measured_regions(job, pol, args):
                     "adds reading the 4 GiB filter file into HBM; value = best of 5 runs, median_value = their median "
                     "(as a child of this process, which keeps its own context on the GPU, some runs have slow "
                     "host-to-device copies; by hand, without the parent, none does)"}
+        if args.e2e_gzip:
+            gz = os.path.join(work, "draft1.fa.gz")
+            t0 = time.perf_counter()
+            gzip_one_stream(draft, gz, min(64, usable_cpus()))
+            t_comp = time.perf_counter() - t0
+            res = {}
+            for tag, extra in (("gunzip", []), ("zlib", ["--tune", "host_zlib=1"])):
+                best = None
+                for _ in range(2):
+                    if os.path.exists(os.path.join(work, "outg_edited.fa")):
+                        os.unlink(os.path.join(work, "outg_edited.fa"))
+                    r = subprocess.run([cli, "-f", gz, "-r", bf, "-b", os.path.join(work, "outg"), "--report"] + extra,
+                                       capture_output=True, text=True, timeout=600)
+                    if r.returncode != 0:
+                        raise RuntimeError(r.stderr[-500:])
+                    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                    if best is None or rep["seconds"] < best["seconds"]:
+                        best = rep
+                res[tag] = {"value": round(best["bases"] / best["seconds"] / 1e6, 2), "unit": "Mbases/s",
+                            "region_s": round(best["seconds"], 4), "fasta_parse_s": best["read_s"],
+                            "polish_batch_calls_s": best["polish_call_s"], "apply_render_write_s": best["write_s"]}
+            out["end_to_end_gzip"] = {
+                **res["gunzip"], "through_zlib": res["zlib"], "compressed_bytes": os.path.getsize(gz),
+                "note": "the same draft as ONE gzip member (deflate level 6, %.1f s to write here): inflate thread -> "
+                        "parser -> batches; best of 2 runs each; through_zlib = the same with zlib's gzread doing "
+                        "the inflating (`--tune host_zlib=1`)" % t_comp}
         if args.e2e_bgzf:
             gz = os.path.join(work, "draft.fa.gz")
             t0 = time.perf_counter()
@@ -255,6 +283,75 @@ def measured_regions(job, pol, args):
             shutil.rmtree(work, ignore_errors=True)
     del host
     return out
+
+
+def _deflate_piece(job):
+    import zlib
+    chunk, last = job
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    return c.compress(chunk) + c.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH), zlib.crc32(chunk), len(chunk)
+
+
+def _crc32_combine(crc1, crc2, len2):
+    """CRC-32 of A+B from CRC-32(A), CRC-32(B) and len(B) (the operator that appends one zero bit to a message,
+    as a 32x32 matrix over GF(2), squared up to len2 bytes)"""
+    def times(mat, vec):
+        s, i = 0, 0
+        while vec:
+            if vec & 1:
+                s ^= mat[i]
+            vec >>= 1
+            i += 1
+        return s
+
+    def square(mat):
+        return [times(mat, mat[n]) for n in range(32)]
+    if len2 == 0:
+        return crc1
+    odd = [0xedb88320] + [1 << (n - 1) for n in range(1, 32)]
+    even = square(odd)
+    odd = square(even)
+    while True:
+        even = square(odd)
+        if len2 & 1:
+            crc1 = times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = square(even)
+        if len2 & 1:
+            crc1 = times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
+
+
+def gzip_one_stream(src, dst, procs):
+    """src as ONE gzip member, written the way pigz does: pieces deflated side by side (each closed by an empty
+    stored block), one header, one trailer"""
+    import multiprocessing as mp
+    import struct
+    piece = 32 << 20
+    size = os.path.getsize(src)
+
+    def jobs():
+        with open(src, "rb") as f:
+            pos = 0
+            while True:
+                chunk = f.read(piece)
+                pos += len(chunk)
+                yield chunk, pos >= size
+                if pos >= size:
+                    break
+    crc, total = 0, 0
+    with mp.Pool(procs) as pool, open(dst, "wb") as o:
+        o.write(b"\x1f\x8b\x08\0\0\0\0\0\0\x03")
+        for data, c, n in pool.imap(_deflate_piece, jobs()):
+            o.write(data)
+            crc = _crc32_combine(crc, c, n)
+            total += n
+        o.write(struct.pack("<II", crc, total & 0xffffffff))
 
 
 def _bgzf_members(chunk):

@@ -20,12 +20,18 @@ constexpr uint32_t F_EOB = 1u << 5, F_LIT = 1u << 6, F_SUB = 1u << 7;
 constexpr unsigned LITLEN_ROOT = 11, DIST_ROOT = 8, PRE_ROOT = 7;
 constexpr unsigned LITLEN_ENTRIES = (1u << LITLEN_ROOT) + 288 * 16;
 constexpr unsigned DIST_ENTRIES = (1u << DIST_ROOT) + 32 * 128;
-// the literal-run table: index = the next FAST_BITS bits of the stream, entry = up to four literals whose codes lie
-// completely inside them (bits 0-7 = bits to drop, bits 8-10 = how many, bits 32-63 = the literals in output
-// order).  A draft is four letters and a newline with codes of two or three bits: one lookup yields 3-4 bases where
-// the symbol-by-symbol walk is a dependent load per base.
-constexpr unsigned FAST_BITS = 9;
+// the run table: index = the next FAST_BITS bits of the stream, entry = what they decode to as far as the codes lie
+// completely inside them: up to four literals, then possibly a length code (bits 0-7 = bits to drop, bits 8-10 =
+// literals, bit 11 = a length follows: base in bits 16-24, extra bits in bits 25-27;
+// bits 32-63 = the literals in output order).  A draft is four letters and a newline with codes of two or three
+// bits and a match every few bases: one look-up yields the literals in front of a match and the match's length,
+// where the symbol-by-symbol walk is a dependent table load per base.  The table is filled for every block, so its
+// width follows the size of the blocks: FAST_BITS when the previous block was a long one (zlib's are 16 K symbols,
+// 80 KB of a draft: 1,024 entries cost 3 % of the block's time), SMALL_FAST_BITS behind a short one.
+constexpr unsigned FAST_BITS = 10, SMALL_FAST_BITS = 6;
 constexpr unsigned FAST_ENTRIES = 1u << FAST_BITS;
+constexpr size_t LONG_BLOCK = 32768;
+constexpr uint64_t P_NLIT = 0x700, P_LEN = 0x800;
 
 const uint16_t LEN_BASE[29] = { 3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
 	                            31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
@@ -194,6 +200,35 @@ build_table(const uint8_t* lens, unsigned n, uint32_t* table, unsigned root, uns
 	return true;
 }
 
+// one entry of the run table, from the literal/length table `lt` (an index whose upper bits are zero finds the entry of
+// a code that fits into the known bits)
+uint64_t
+run_entry(const uint32_t* lt, unsigned idx, unsigned width)
+{
+	unsigned used = 0, cnt = 0;
+	uint64_t lits = 0, tail = 0;
+	for (;;) {
+		const uint32_t e = lt[idx >> used];
+		const unsigned l = e & 31;
+		if ((e & (F_SUB | F_EOB)) || l == 0 || used + l > width) {
+			break;
+		}
+		if (e & F_LIT) {
+			if (cnt == 4) {
+				break;
+			}
+			lits |= (uint64_t)((e >> 16) & 0xff) << (8 * cnt);
+			cnt++;
+			used += l;
+			continue;
+		}
+		tail = P_LEN | ((uint64_t)(e >> 16) << 16) | ((uint64_t)((e >> 8) & 7) << 25);
+		used += l;
+		break;
+	}
+	return (lits << 32) | tail | (cnt << 8) | used;
+}
+
 } // namespace
 
 Gunzip::Gunzip()
@@ -216,6 +251,9 @@ Gunzip::Gunzip()
   , window_(nullptr)
   , litlen_(nullptr)
   , dist_(nullptr)
+  , run_bits_(FAST_BITS)
+  , block_bytes_(0)
+  , prev_block_bytes_(LONG_BLOCK)
 {
 }
 
@@ -283,7 +321,7 @@ Gunzip::open(const char* path)
 	}
 	inbuf_ = (unsigned char*)malloc(INBUF + INPAD);
 	window_ = (unsigned char*)calloc(WINDOW, 1);
-	// (the literal-run table lives behind the literal/length table: FAST_ENTRIES 8-byte entries)
+	// (the run table lives behind the literal/length table: FAST_ENTRIES 8-byte entries)
 	litlen_ = (uint32_t*)malloc(sizeof(uint32_t) * LITLEN_ENTRIES + sizeof(uint64_t) * FAST_ENTRIES + 8);
 	dist_ = (uint32_t*)malloc(sizeof(uint32_t) * DIST_ENTRIES);
 	if (!inbuf_ || !window_ || !litlen_ || !dist_) {
@@ -490,23 +528,13 @@ Gunzip::parse_block_()
 	if (!build_table(lens + 288, ndist, dist_, DIST_ROOT, DIST_ENTRIES, K_DIST)) {
 		return fail_("invalid distances set");
 	}
-	// literal runs: what the next FAST_BITS bits decode to as long as they are literals with complete codes
-	uint64_t* fast = (uint64_t*)(litlen_ + LITLEN_ENTRIES + (LITLEN_ENTRIES & 1));
-	for (unsigned idx = 0; idx < FAST_ENTRIES; idx++) {
-		unsigned used = 0, cnt = 0;
-		uint64_t lits = 0;
-		while (cnt < 4) {
-			const uint32_t e = litlen_[idx >> used]; // (the index bits above the known ones are zero: only an entry
-			                                         // whose code fits into the known bits is taken)
-			const unsigned l = e & 31;
-			if (!(e & F_LIT) || (e & F_SUB) || l == 0 || used + l > FAST_BITS) {
-				break;
-			}
-			lits |= (uint64_t)((e >> 16) & 0xff) << (8 * cnt);
-			used += l;
-			cnt++;
+	{
+		run_bits_ = prev_block_bytes_ >= LONG_BLOCK ? FAST_BITS : SMALL_FAST_BITS;
+		uint64_t* const fast = (uint64_t*)(litlen_ + LITLEN_ENTRIES + (LITLEN_ENTRIES & 1));
+		for (unsigned idx = 0; idx < (1u << run_bits_); idx++) {
+			fast[idx] = run_entry(litlen_, idx, run_bits_);
 		}
-		fast[idx] = (lits << 32) | (cnt << 8) | used;
+		block_bytes_ = 0;
 	}
 	stage_ = ST_HUFFMAN;
 	return true;
@@ -584,45 +612,60 @@ Gunzip::read(unsigned char* dst, size_t want)
 		bits >>= (n);                                                                                                      \
 		nbits -= (n);                                                                                                      \
 	} while (0)
-			// One pass of the loop = the literals in front of a match (up to five look-ups in the literal-run table
-			// fit into one refill), then the match.
+			// One pass of the loop = the literals in front of a match and the match: up to three look-ups in the run
+			// table (33 bits), the length's extra bits, a refill, the distance.
+#define NTE_RUN(p)                                                                                                         \
+	do {                                                                                                                   \
+		p = fast[bits & fmask];                                                                                            \
+		memcpy(out, (const unsigned char*)&p + 4, 4);                                                                      \
+		out += (p >> 8) & 7;                                                                                               \
+		NTE_DROP((unsigned)p & 0xff);                                                                                      \
+	} while (0)
+			const uint64_t fmask = (1u << run_bits_) - 1;
+			unsigned char* const out0 = out;
 			while (out < out_end && in <= in_lim) {
 				NTE_REFILL();
-				uint64_t f = fast[bits & (FAST_ENTRIES - 1)];
-				if (f & 0x700) {
-					int more = 4;
-					do {
-						memcpy(out, (const unsigned char*)&f + 4, 4);
-						out += (f >> 8) & 7;
-						NTE_DROP((unsigned)f & 0xff);
-						f = fast[bits & (FAST_ENTRIES - 1)];
-					} while ((f & 0x700) && more-- > 0);
-					if (f & 0x700) {
-						continue; // a long run
+				uint64_t p;
+				NTE_RUN(p);
+				if (!(p & P_LEN) && (p & P_NLIT)) {
+					NTE_RUN(p);
+					if (!(p & P_LEN) && (p & P_NLIT)) {
+						NTE_RUN(p);
+						if (!(p & P_LEN) && (p & P_NLIT)) {
+							continue; // a long run of literals
+						}
 					}
+				}
+				unsigned lbase, xl;
+				if (p & P_LEN) {
+					lbase = (unsigned)(p >> 16) & 0x1ff;
+					xl = (unsigned)(p >> 25) & 7;
+				} else {
+					// neither a literal nor a length that the run table knows: a long code, or the end of the block
 					NTE_REFILL();
+					uint32_t e = lt[bits & ((1u << LITLEN_ROOT) - 1)];
+					if (e & F_SUB) {
+						NTE_DROP(LITLEN_ROOT);
+						e = lt[(e >> 16) + (bits & ((1u << ((e >> 8) & 31)) - 1))];
+					}
+					const unsigned l = e & 31;
+					if (l == 0) {
+						err = "invalid literal/length code";
+						break;
+					}
+					NTE_DROP(l);
+					if (e & F_LIT) {
+						*out++ = (unsigned char)(e >> 16);
+						continue;
+					}
+					if (e & F_EOB) {
+						block_done = true;
+						break;
+					}
+					lbase = e >> 16;
+					xl = (e >> 8) & 31;
 				}
-				uint32_t e = lt[bits & ((1u << LITLEN_ROOT) - 1)];
-				if (e & F_SUB) {
-					NTE_DROP(LITLEN_ROOT);
-					e = lt[(e >> 16) + (bits & ((1u << ((e >> 8) & 31)) - 1))];
-				}
-				const unsigned l = e & 31;
-				if (l == 0) {
-					err = "invalid literal/length code";
-					break;
-				}
-				NTE_DROP(l);
-				if (e & F_LIT) {
-					*out++ = (unsigned char)(e >> 16); // a longer run of literals, or one with a long code
-					continue;
-				}
-				if (e & F_EOB) {
-					block_done = true;
-					break;
-				}
-				const unsigned xl = (e >> 8) & 31;
-				const unsigned length = (e >> 16) + (unsigned)(bits & ((1u << xl) - 1));
+				const unsigned length = lbase + (unsigned)(bits & ((1u << xl) - 1));
 				NTE_DROP(xl);
 				NTE_REFILL(); // (a distance code with its extra bits takes up to 28 bits)
 				uint32_t d = dt[bits & ((1u << DIST_ROOT) - 1)];
@@ -667,11 +710,13 @@ Gunzip::read(unsigned char* dst, size_t want)
 					} while (o < out);
 				}
 			}
+#undef NTE_RUN
 #undef NTE_REFILL
 #undef NTE_DROP
 			bits_ = bits;
 			nbits_ = nbits;
 			in_ = in;
+			block_bytes_ += (size_t)(out - out0);
 			if (err) {
 				fail_(err);
 				break;
@@ -681,6 +726,7 @@ Gunzip::read(unsigned char* dst, size_t want)
 				break;
 			}
 			if (block_done) {
+				prev_block_bytes_ = block_bytes_;
 				stage_ = final_block_ ? ST_TRAILER : ST_BLOCK;
 			} else if (out < out_end && file_eof_ && in_ > in_lim) {
 				fail_("unexpected end of file");

@@ -4,8 +4,8 @@
 // ntedit.cpp:25); zlib's inflate decodes one symbol per table walk and tops out at a third of a Gbase/s, which
 // makes the inflate thread the slowest stage of the whole polishing run on the reference demo's own input format.
 // This decoder is written for that stream shape (long dynamic-Huffman blocks, four hot literals, short matches):
-// a 64-bit bit buffer refilled without branches, an 11-bit first-level table for the literal/length code, up to
-// three literals per refill, matches copied eight bytes at a time.  It produces the output block by block
+// a 64-bit bit buffer refilled without branches, a run table that yields the literals in front of a match together
+// with the match's length in one look-up, matches copied eight bytes at a time.  It produces the output block by block
 // (FastaReader's 4 MiB slots) and keeps the 32 KiB window between calls.
 //
 // What it returns is what gzread would: concatenated members are decoded one after the other, bytes after the last
@@ -79,6 +79,8 @@ class Gunzip
 	unsigned char* window_; // the last WINDOW bytes produced (valid: min(WINDOW, member_out_))
 	uint32_t* litlen_;
 	uint32_t* dist_;
+	unsigned run_bits_;                     // index bits of the run table of the current block
+	size_t block_bytes_, prev_block_bytes_; // output of the current / the previous Huffman block
 };
 
 } // namespace nte_host

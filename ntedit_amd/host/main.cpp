@@ -393,6 +393,11 @@ main(int argc, char** argv)
 		exit(EXIT_FAILURE);
 	}
 	for (const auto& t : tunes) {
+		if (t.first == "host_zlib") {
+			// (a host-side switch, not the library's: 1 = inflate .gz drafts through zlib instead of host/gunzip.cpp)
+			nte_host::set_gzip_through_zlib((int)t.second);
+			continue;
+		}
 		if (ntedit_hip_set_tuning(ctx, t.first.c_str(), t.second) != 0) {
 			fprintf(stderr, PROGRAM ": error: %s\n", ntedit_hip_last_error(ctx));
 			exit(EXIT_FAILURE);

@@ -210,3 +210,121 @@ def test_reader_backends_agree(tmp_path):
                 assert lib.hostsim_fasta_io_error(ctypes.c_char_p(p.encode())) == 1, backend
     finally:
         lib.hostsim_gzip_through_zlib(0)
+
+
+class BitWriter:
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def bits(self, value, count):  # LSB first (header fields, extra bits)
+        self.acc |= value << self.n
+        self.n += count
+        while self.n >= 8:
+            self.out.append(self.acc & 0xff)
+            self.acc >>= 8
+            self.n -= 8
+
+    def code(self, code, length):  # a Huffman code: most significant bit first
+        for i in range(length - 1, -1, -1):
+            self.bits((code >> i) & 1, 1)
+
+    def done(self):
+        if self.n:
+            self.out.append(self.acc & 0xff)
+        return bytes(self.out)
+
+
+def canonical(lengths):
+    codes, code = {}, 0
+    for ln in range(1, 16):
+        for sym in sorted(s for s, l in lengths.items() if l == ln):
+            codes[sym] = (code, ln)
+            code += 1
+        code <<= 1
+    return codes
+
+
+LEN_SYMS = {257: (3, 0), 258: (4, 0), 259: (5, 0), 260: (6, 0), 261: (7, 0), 262: (8, 0), 263: (9, 0), 264: (10, 0), 265: (11, 1), 266: (13, 1)}
+DIST_SYMS = [(1, 0), (2, 0), (3, 0), (4, 0), (5, 1), (7, 1), (9, 2), (13, 2), (17, 3), (25, 3), (33, 4), (49, 4), (65, 5), (97, 5), (129, 6), (193, 6)]
+
+
+def crafted_block(symbols, lit_lengths, dist_lengths, final=1):
+    """a dynamic-Huffman block with exactly these code lengths; symbols = literals (ints) and (length symbol, extra,
+    distance symbol, extra) tuples"""
+    w = BitWriter()
+    w.bits(final, 1)
+    w.bits(2, 2)
+    nlit, ndist = 286, 30
+    w.bits(nlit - 257, 5)
+    w.bits(ndist - 1, 5)
+    w.bits(19 - 4, 4)
+    pre = {s: 5 for s in range(16)}
+    pre.update({16: 2, 17: 3, 18: 3})
+    for s in (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15):
+        w.bits(pre[s], 3)
+    pc = canonical(pre)
+    for i in range(nlit):
+        w.code(*pc[lit_lengths.get(i, 0)])
+    for i in range(ndist):
+        w.code(*pc[dist_lengths.get(i, 0)])
+    lc, dc = canonical(lit_lengths), canonical(dist_lengths)
+    for s in symbols:
+        if isinstance(s, int):
+            w.code(*lc[s])
+        else:
+            ls, lx, ds, dx = s
+            w.code(*lc[ls])
+            w.bits(lx, LEN_SYMS[ls][1])
+            w.code(*dc[ds])
+            w.bits(dx, DIST_SYMS[ds][1])
+    if 256 in lc:
+        w.code(*lc[256])
+    return w.done()
+
+
+def test_gunzip_crafted_code_lengths(tmp_path):
+    """codes of every length from 1 to 15 in both alphabets (second-level tables of every size), every length and
+    distance symbol of the set with its extra bits; zlib is the judge of what the stream says"""
+    lit_lengths = {65: 1, 67: 2, 71: 3, 84: 4, 10: 5, 256: 6, 257: 7, 258: 8, 259: 9, 260: 10, 261: 11, 262: 12, 263: 13, 264: 14, 265: 15, 266: 15}
+    dist_lengths = {i: i + 1 for i in range(15)}
+    dist_lengths[15] = 15
+    rng = np.random.default_rng(4)
+    symbols = [int(x) for x in rng.choice([65, 67, 71, 84, 10], 300)]
+    for rep in range(40):
+        for ls in LEN_SYMS:
+            ds = int(rng.integers(0, 16))
+            symbols.append((ls, int(rng.integers(0, 1 << LEN_SYMS[ls][1])), ds, int(rng.integers(0, 1 << DIST_SYMS[ds][1]))))
+            symbols += [int(x) for x in rng.choice([65, 67, 71, 84, 10], int(rng.integers(0, 6)))]
+    raw = crafted_block(symbols, lit_lengths, dist_lengths)
+    data = zlib.decompress(raw, -15)
+    assert len(data) > 2000
+    p = str(tmp_path / "in.gz")
+    with open(p, "wb") as f:
+        f.write(gz_header() + raw + struct.pack("<II", zlib.crc32(data), len(data)))
+    for block in (1 << 16, 50, 1):
+        rc, got = gunzip(p, tmp_path, block)
+        assert rc == len(data) and got == data, block
+    # the same with a match that reaches behind the start of the output: zlib and the decoder both refuse
+    bad = crafted_block([65, 67, (257, 0, 4, 1)], lit_lengths, dist_lengths)
+    with pytest.raises(zlib.error):
+        zlib.decompress(bad, -15)
+    with open(p, "wb") as f:
+        f.write(gz_header() + bad + struct.pack("<II", 0, 0))
+    assert gunzip(p, tmp_path)[0] == -3
+    # code length sets zlib rejects: over-subscribed, incomplete (either alphabet), no end-of-block code
+    no_eob = {k: v for k, v in lit_lengths.items() if k != 256}
+    no_eob[66] = 6
+    for lit, dist in (({**lit_lengths, 66: 1}, dist_lengths), ({k: v for k, v in lit_lengths.items() if k != 266}, dist_lengths),
+                      (lit_lengths, {k: v for k, v in dist_lengths.items() if k != 15}), (no_eob, dist_lengths)):
+        w = crafted_block([65, 67], lit, dist)
+        with pytest.raises(zlib.error):
+            zlib.decompress(w, -15)
+        with open(p, "wb") as f:
+            f.write(gz_header() + w + struct.pack("<II", 0, 0))
+        assert gunzip(p, tmp_path)[0] == -3
+    # a single distance code of one bit is an incomplete set zlib accepts
+    one = crafted_block([65, 67, 71, 84, (257, 0, 0, 0), 10], lit_lengths, {0: 1})
+    data = zlib.decompress(one, -15)
+    with open(p, "wb") as f:
+        f.write(gz_header() + one + struct.pack("<II", zlib.crc32(data), len(data)))
+    assert gunzip(p, tmp_path) == (len(data), data)

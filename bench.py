@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--e2e-gzip", action="store_true", help="also run the end-to-end region on the draft as ONE gzip stream (level 6), "
                     "inflated by host/gunzip.cpp and, for comparison, by zlib")
     ap.add_argument("--e2e-bgzf", action="store_true", help="also run the end-to-end region on a BGZF-compressed draft")
+    ap.add_argument("--no-e2e", action="store_true", help="of the two extra regions, skip the end-to-end one (the `ntedit` binary)")
     ap.add_argument("--no-regions", action="store_true", help="skip the host-buffer and end-to-end regions (N=1)")
     ap.add_argument("--snv", action="store_true",
                     help="N=1 side line: -s 1 (every position re-assessed, ntedit.cpp:1806,1865; -i/-d 0)")
@@ -181,6 +182,9 @@ def measured_regions(job, pol, args):
                     "(wall clock, best of 2 after a warm-up); H2D in pieces overlapped with screening"}
     except Exception as e:  # pragma: no cover
         out["kernel_region_host"] = {"error": str(e)}
+    if args.no_e2e:
+        del host
+        return out
     cli = os.path.join(ROOT, "ntedit_amd", "ntedit")
     work = tempfile.mkdtemp(prefix="ntedit_bench_e2e_")
     try:

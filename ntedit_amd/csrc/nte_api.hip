@@ -94,6 +94,7 @@ struct ntedit_hip_ctx
 	DevBuf offs, lens;
 	DevBuf bin_records[2], bin_fill[2], bin_ctl[2], bin_ovf[2], bin_lost; // (two sets: chunk j + 1 is partitioned while chunk j is probed)
 	hipStream_t stream3 = nullptr;    // the probe stage of the binned screening when it overlaps the partition stage
+	hipStream_t stream_copy = nullptr; // H2D pieces of a host batch that is polished in pipeline chunks (stream2 runs the event machine then)
 	bool bin_fallback = false;        // an overflow list overflowed: this context screens with the direct kernel from now on
 	struct Tuning                     // ntedit_hip_set_tuning(): test / tuning knobs, none of which can change a result
 	{
@@ -112,6 +113,7 @@ struct ntedit_hip_ctx
 		u32 records_uncached = 0; // the screening records in memory the L2 does not keep (experiments)
 		u32 bin_scatter = 0;      // partition kernel: 0 barrier-phased (k_wc_scatter_b), 1 barrier-free (k_wc_scatter)
 		u32 bin_overlap = 0;      // partition chunk j + 1 while chunk j is probed (two record buffers, a second stream)
+		u32 h2d_chunks = 0;       // a large batch in host memory is polished in this many pipeline chunks (0, 1: one)
 	} tune;
 	DevBuf ev_cover, ev_before, ev_flags, ev_list, ev_bmax; // event rounds
 	u32 cu_count = 256;
@@ -847,6 +849,10 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 	for (auto& e : c->bin_ev) {
 		(void)hipEventDestroy(e);
 	}
+	if (c->stream_copy) {
+		(void)hipStreamSynchronize(c->stream_copy);
+		(void)hipStreamDestroy(c->stream_copy);
+	}
 	if (c->stream3) {
 		(void)hipStreamSynchronize(c->stream3);
 		(void)hipStreamDestroy(c->stream3);
@@ -1368,6 +1374,13 @@ PolishRun::plan()
 		u64 target = n + 1;
 		if (c->tune.chunk_bytes) { // tests: force many chunks
 			target = c->tune.chunk_bytes;
+		} else if (h2d_overlap && c->tune.h2d_chunks > 1 && n >= (1ULL << 30)) {
+			// A batch that is still crossing PCIe looked like another matter -- the screening waits for the link most
+			// of the time, the event machine of the chunks that have arrived could run underneath the copy of the
+			// rest -- and is not: 3 Gbp from page-locked memory, 158 ms in one chunk, 198 / 199 / 206 / 223 ms in
+			// 4 / 8 / 12 / 16 (the screening next to the machine and the copy takes 166-174 ms instead of 112).
+			// Off unless asked for (`h2d_chunks`).
+			target = n / c->tune.h2d_chunks + 1;
 		}
 		u32 c0 = 0;
 		u64 t_prev = 0;
@@ -1456,17 +1469,18 @@ PolishRun::launch_screening(int attempt)
 	u32 slog_unused = 0, nsl_unused = 0;
 	const bool binned = binned_applicable(c, f0, n, &slog_unused, &nsl_unused);
 	const u64 n_pieces = h2d_piece ? (n + h2d_piece - 1) / h2d_piece : 0;
-	if (h2d_overlap && attempt == 0 && !pipelined) {
+	if (h2d_overlap && attempt == 0) {
 		while (c->h2d_ev.size() < n_pieces) {
 			hipEvent_t e;
 			HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
 			c->h2d_ev.push_back(e);
 		}
 	}
+	hipStream_t s_copy = sB;
 	auto copy_piece = [&](u64 j) -> hipError_t {
 		const u64 o = j * h2d_piece, len = o + h2d_piece < n ? h2d_piece : n - o;
-		hipError_t e = hipMemcpyAsync((char*)c->seq.p + o, bases + o, len, hipMemcpyHostToDevice, sB);
-		return e != hipSuccess ? e : hipEventRecord(c->h2d_ev[j], sB);
+		hipError_t e = hipMemcpyAsync((char*)c->seq.p + o, bases + o, len, hipMemcpyHostToDevice, s_copy);
+		return e != hipSuccess ? e : hipEventRecord(c->h2d_ev[j], s_copy);
 	};
 	if (!pipelined && h2d_overlap && attempt == 0 && !binned) {
 		// direct kernel: piece j+1 is copied (stream B is idle until the screening is done) while piece j is
@@ -1508,8 +1522,20 @@ PolishRun::launch_screening(int attempt)
 		}
 		HIP_TRY(c, hipEventRecord(c->chunk_ev[1], sA));
 	} else {
+		c->h2d_piece_bytes = 0;
 		if (h2d_overlap && attempt == 0) {
-			HIP_TRY(c, hipMemcpyAsync(c->seq.p, bases, n, hipMemcpyHostToDevice, sA));
+			// the pieces cross on a stream of their own (stream B runs the event machine of the chunks that are
+			// through), every chunk's screening waits for its own bases
+			if (!c->stream_copy) {
+				HIP_TRY(c, hipStreamCreate(&c->stream_copy));
+			}
+			s_copy = c->stream_copy;
+			HIP_TRY(c, hipStreamWaitEvent(s_copy, c->ev[0], 0)); // (behind whatever the earlier work on stream A still reads)
+			for (u64 j = 0; j < n_pieces; j++) {
+				HIP_TRY(c, copy_piece(j));
+			}
+			c->h2d_piece_bytes = h2d_piece;
+			c->h2d_pieces = n_pieces;
 		}
 		u32 slog = 0, nsl = 0;
 		const bool bin_chunks = binned_applicable(c, f0, n, &slog, &nsl);
@@ -1518,6 +1544,11 @@ PolishRun::launch_screening(int attempt)
 		}
 		for (size_t j = 0; j < n_ch; j++) {
 			HIP_TRY(c, hipEventRecord(c->chunk_ev[2 * j], sA));
+			if (c->h2d_piece_bytes && !bin_chunks) {
+				u64 piece = (chunks[j].t1 * SCREEN_TILE + SCREEN_TILE) / c->h2d_piece_bytes;
+				piece = piece < n_pieces ? piece : n_pieces - 1;
+				HIP_TRY(c, hipStreamWaitEvent(sA, c->h2d_ev[piece], 0));
+			}
 			if (bin_chunks) {
 				// (the probe stage of chunk j+1 leaves room on the CUs for the event machine of chunk j)
 				const u64 p0 = chunks[j].t0 * SCREEN_TILE, p1 = chunks[j].t1 * SCREEN_TILE;
@@ -1530,6 +1561,7 @@ PolishRun::launch_screening(int attempt)
 			}
 			HIP_TRY(c, hipEventRecord(c->chunk_ev[2 * j + 1], sA));
 		}
+		c->h2d_piece_bytes = 0;
 	}
 	HIP_TRY(c, hipEventRecord(c->ev[1], sA));
 	return 0;
@@ -2537,6 +2569,8 @@ ntedit_hip_set_tuning(ntedit_hip_ctx* c, const char* key, uint64_t value)
 		t.bin_scatter = (u32)value;
 	} else if (k == "bin_overlap") {
 		t.bin_overlap = (u32)value;
+	} else if (k == "h2d_chunks") {
+		t.h2d_chunks = (u32)value;
 	} else if (k == "records_uncached") {
 		t.records_uncached = (u32)value;
 		for (int q = 0; q < 2; q++) {

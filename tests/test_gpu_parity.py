@@ -292,16 +292,21 @@ def test_polish_chunk_pipeline(tmp_path, ci, screen_mode, oracle_build):
         assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / (g + "_edited.fa")), shallow=False)
 
 
+@pytest.mark.parametrize("chunked", [0, 1])
 @pytest.mark.parametrize("screen_mode", [1, 2])
-def test_polish_batch_arriving_in_pieces(tmp_path, screen_mode, oracle_build):
+def test_polish_batch_arriving_in_pieces(tmp_path, screen_mode, chunked, oracle_build):
     """a batch in host memory crosses PCIe in pieces while the pieces that have arrived are screened (direct kernel:
-    tile ranges per piece; partitioned pipeline: record chunks that grow, each waiting for its own pieces): same bytes"""
+    tile ranges per piece; partitioned pipeline: record chunks that grow, each waiting for its own pieces): same bytes.
+    chunked: the batch is polished in pipeline chunks at the same time (the pieces cross on a stream of their own, the
+    event machine of a chunk runs while later chunks arrive)"""
     case_kw, par_kw = H.PARITY_CONFIGS[0]
     case = H.make_case(str(tmp_path), 6500 + screen_mode, **dict(case_kw, contigs=6, n=120000))
     hp = H.default_params(**par_kw)
     H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), case["rep"])
     pol = _fresh()
     pol.set_tuning("h2d_piece", 4 * 16384)
+    if chunked:
+        pol.set_tuning("chunk_bytes", 250000)
     try:
         _load_filters(pol, case)
         pol.set_params(_hip_params(screen_mode=screen_mode, **par_kw))

@@ -10,9 +10,8 @@ namespace nte_host {
 
 namespace {
 
-constexpr size_t INBUF = 4u << 20;
 constexpr size_t INPAD = 64;         // zero bytes kept behind the data: the bit reader loads eight bytes at a time
-constexpr size_t IN_LOW = 256 << 10; // the buffer is topped up below this (a header, a block header and one run fit)
+constexpr size_t IN_LOW = 256 << 10; // the buffer is topped up below this (a member header or a block header fits)
 
 // entry of a decode table: bits 0-4 = code bits to drop, bit 5 end of block, bit 6 literal, bit 7 sub-table,
 // bits 8-12 = extra bits (or the sub-table's index bits), bits 16-31 = literal / base value / sub-table offset
@@ -231,8 +230,10 @@ run_entry(const uint32_t* lt, unsigned idx, unsigned width)
 
 } // namespace
 
-Gunzip::Gunzip()
-  : fd_(-1)
+Gunzip::Gunzip(size_t in_bytes)
+  : inbuf_size_(in_bytes < 2048 ? 2048 : in_bytes)
+  , in_low_(IN_LOW < inbuf_size_ / 2 ? IN_LOW : inbuf_size_ / 2)
+  , fd_(-1)
   , file_eof_(false)
   , inbuf_(nullptr)
   , in_(nullptr)
@@ -279,21 +280,23 @@ Gunzip::fail_(const char* what)
 	return false;
 }
 
-// tops the input buffer up; the bytes the bit reader holds are not touched (they were consumed from the buffer)
+// tops the input buffer up
 bool
 Gunzip::fill_input_()
 {
-	if (file_eof_ || avail_in_() >= IN_LOW) {
+	if (file_eof_ || avail_in_() >= in_low_) {
 		return true;
 	}
-	const size_t keep = in_ < in_end_ ? avail_in_() : 0;
 	if (in_ > in_end_) {
 		return true; // (only at the end of the file)
 	}
-	memmove(inbuf_, in_, keep);
+	// (the whole bytes the bit reader holds stay in front of in_: a stored block or a trailer hands them back)
+	const size_t back = (size_t)(nbits_ >> 3) < (size_t)(in_ - inbuf_) ? (size_t)(nbits_ >> 3) : (size_t)(in_ - inbuf_);
+	const size_t keep = avail_in_() + back;
+	memmove(inbuf_, in_ - back, keep);
 	size_t have = keep;
-	while (have < INBUF) {
-		const ssize_t r = ::read(fd_, inbuf_ + have, INBUF - have);
+	while (have < inbuf_size_) {
+		const ssize_t r = ::read(fd_, inbuf_ + have, inbuf_size_ - have);
 		if (r < 0) {
 			if (errno == EINTR) {
 				continue;
@@ -306,7 +309,7 @@ Gunzip::fill_input_()
 		}
 		have += (size_t)r;
 	}
-	in_ = inbuf_;
+	in_ = inbuf_ + back;
 	in_end_ = inbuf_ + have;
 	memset(inbuf_ + have, 0, INPAD);
 	return true;
@@ -319,7 +322,7 @@ Gunzip::open(const char* path)
 	if (fd_ < 0) {
 		return false;
 	}
-	inbuf_ = (unsigned char*)malloc(INBUF + INPAD);
+	inbuf_ = (unsigned char*)malloc(inbuf_size_ + INPAD);
 	window_ = (unsigned char*)calloc(WINDOW, 1);
 	// (the run table lives behind the literal/length table: FAST_ENTRIES 8-byte entries)
 	litlen_ = (uint32_t*)malloc(sizeof(uint32_t) * LITLEN_ENTRIES + sizeof(uint64_t) * FAST_ENTRIES + 8);
@@ -590,10 +593,11 @@ Gunzip::read(unsigned char* dst, size_t want)
 			if (!fill_input_()) {
 				break;
 			}
-			// while more of the file is to come the loop stops eight bytes short of the buffered data (the zero
-			// padding must not be taken for data); at the end of the file it runs into the padding and the
-			// overrun test below tells a complete stream from a truncated one
-			const unsigned char* const in_lim = file_eof_ ? in_end_ + 8 : in_end_ - 8;
+			// while more of the file is to come the loop stops 32 bytes short of the buffered data: one pass refills
+			// up to three times, each refill moves on by up to seven bytes and loads eight, and none of that may
+			// reach the zero padding and take it for data; at the end of the file the loop runs into the padding and
+			// the overrun test below tells a complete stream from a truncated one
+			const unsigned char* const in_lim = file_eof_ ? in_end_ + 8 : in_end_ - 32;
 			const uint32_t* const lt = litlen_;
 			const uint32_t* const dt = dist_;
 			uint64_t bits = bits_;

@@ -25,7 +25,8 @@ class Gunzip
 	// room the caller keeps writable beyond `want` bytes of a read() (a match may overrun the request)
 	static constexpr size_t SLACK = 320;
 
-	Gunzip();
+	// in_bytes: size of the buffer the compressed file is read through (tests make it small: every refill is a seam)
+	explicit Gunzip(size_t in_bytes = 4u << 20);
 	~Gunzip();
 	Gunzip(const Gunzip&) = delete;
 	Gunzip& operator=(const Gunzip&) = delete;
@@ -60,6 +61,7 @@ class Gunzip
 	void refill_();
 	size_t avail_in_() const { return (size_t)(in_end_ - in_); }
 
+	size_t inbuf_size_, in_low_;
 	int fd_;
 	bool file_eof_;
 	unsigned char* inbuf_;

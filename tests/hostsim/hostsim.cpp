@@ -434,14 +434,14 @@ hostsim_gzip_through_zlib(int on)
 }
 
 // TEST-ONLY: inflates a .gz file with host/gunzip.cpp alone into out_path, `block` bytes per read() call (so that tests
-// can put the block boundaries anywhere).  Returns the bytes written; -1 not a gzip file, -2 output, -3 the stream
+// can put the block boundaries anywhere), the compressed file read through a buffer of in_bytes (0: the default).  Returns the bytes written; -1 not a gzip file, -2 output, -3 the stream
 // failed (what it produced up to there is in the file), -4 a member's CRC-32 or length does not match its trailer
 #include "../../ntedit_amd/host/gunzip.h"
 #include <zlib.h>
 extern "C" long long
-hostsim_gunzip(const char* in_path, const char* out_path, unsigned block)
+hostsim_gunzip_buffers(const char* in_path, const char* out_path, unsigned block, unsigned in_bytes)
 {
-	nte_host::Gunzip g;
+	nte_host::Gunzip g(in_bytes ? in_bytes : (4u << 20));
 	if (!g.open(in_path)) {
 		return -1;
 	}
@@ -474,6 +474,12 @@ hostsim_gunzip(const char* in_path, const char* out_path, unsigned block)
 	}
 	fclose(o);
 	return g.failed() ? -3 : mismatch ? -4 : total;
+}
+
+extern "C" long long
+hostsim_gunzip(const char* in_path, const char* out_path, unsigned block)
+{
+	return hostsim_gunzip_buffers(in_path, out_path, block, 0);
 }
 
 // TEST-ONLY: the same dump through the mapped, multi-threaded reader (ntedit_amd/host/fasta_map.cpp);

@@ -13,11 +13,12 @@ import pytest
 import helpers as H
 
 
-def gunzip(path, tmp_path, block=1 << 16):
+def gunzip(path, tmp_path, block=1 << 16, in_bytes=0):
     lib = H.hostsim_lib()
-    lib.hostsim_gunzip.restype = ctypes.c_longlong
+    lib.hostsim_gunzip_buffers.restype = ctypes.c_longlong
     out = str(tmp_path / "out.bin")
-    rc = lib.hostsim_gunzip(ctypes.c_char_p(path.encode()), ctypes.c_char_p(out.encode()), ctypes.c_uint(block))
+    rc = lib.hostsim_gunzip_buffers(ctypes.c_char_p(path.encode()), ctypes.c_char_p(out.encode()), ctypes.c_uint(block),
+                                    ctypes.c_uint(in_bytes))
     data = b""
     if rc != -1 and rc != -2:
         with open(out, "rb") as f:
@@ -328,3 +329,22 @@ def test_gunzip_crafted_code_lengths(tmp_path):
     with open(p, "wb") as f:
         f.write(gz_header() + one + struct.pack("<II", zlib.crc32(data), len(data)))
     assert gunzip(p, tmp_path) == (len(data), data)
+
+
+@pytest.mark.parametrize("enc", ["default", "fast", "fixed", "stored", "small_blocks"])
+def test_gunzip_input_buffer_seams(tmp_path, enc):
+    """the compressed file read through buffers of a few KB: thousands of places where the decoder has to stop short of
+    the buffered bytes and carry on after the refill, at every alignment"""
+    rng = np.random.default_rng(12)
+    data = dna(rng, 1_500_000) + PAYLOADS["text"][:200000] + PAYLOADS["random"][:50000]
+    z = deflate(data, **dict(ENCODINGS)[enc])
+    p = str(tmp_path / "in.gz")
+    with open(p, "wb") as f:
+        f.write(z)
+    for in_bytes in (2048, 2049, 3001, 4096, 5003, 8192 + 7, 65536):
+        rc, got = gunzip(p, tmp_path, 1 << 20, in_bytes)
+        assert rc == len(data) and got == data, (enc, in_bytes, rc)
+    for cut in (len(z) // 3, len(z) - 5):
+        with open(p, "wb") as f:
+            f.write(z[:cut])
+        assert gunzip(p, tmp_path, 1 << 20, 2048)[0] == -3

@@ -114,7 +114,7 @@ def main():
                     cmd += ["-t", str(int(rng.integers(1, 9)))]
                 zdraw = rng.random()
                 if zdraw < 0.25:
-                    subprocess.run(["gzip", "-k", "-1", case["draft"]], check=True)
+                    subprocess.run(["gzip", "-k", "-%d" % int(rng.choice([1, 6, 9])), case["draft"]], check=True)
                     cmd[cmd.index("-f") + 1] = case["draft"] + ".gz"
                 elif zdraw < 0.4:
                     from test_fasta_reader import bgzf_bytes  # (bgzip container: inflated member by member, in parallel)

@@ -671,7 +671,9 @@ Gunzip::read(unsigned char* dst, size_t want)
 				}
 				const unsigned length = lbase + (unsigned)(bits & ((1u << xl) - 1));
 				NTE_DROP(xl);
-				NTE_REFILL(); // (a distance code with its extra bits takes up to 28 bits)
+				if (nbits < 32) { // (a distance code with its extra bits takes up to 28 bits)
+					NTE_REFILL();
+				}
 				uint32_t d = dt[bits & ((1u << DIST_ROOT) - 1)];
 				if (d & F_SUB) {
 					NTE_DROP(DIST_ROOT);

@@ -350,10 +350,12 @@ void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
  * implementations that are bit-identical by construction (and tested to be), split work differently, or print
  * timings.  Keys: "screen_mode" (overrides params.screen_mode), "bin_chunk" (k-mer starts per record chunk of the
  * partitioned screening), "bin_cap_percent" (record-run capacity in percent of the expectation: forces the overflow
- * list), "bin_fallback" (1: direct kernel from now on, as after a lost overflow), "bin_scatter" (1: the barrier-free partition kernel), "bin_overlap" (partition a record chunk while the previous one is probed), "probe_parts_log2",
- * "force_xcc" (x + 1: the probe
- * stage behaves as if every wavefront ran on XCD x), "bin_timing", "chunk_bytes" (pipeline chunk size), "h2d_piece"
- * (bytes per host-to-device piece), "inline_tries", "screen_lds_pad", "no_rounds", "force_rounds", "no_early_copy", "no_lds_ws".
+ * list), "bin_fallback" (1: direct kernel from now on, as after a lost overflow), "bin_scatter" (1: the barrier-free
+ * partition kernel), "bin_overlap" (partition a record chunk while the previous one is probed), "probe_parts_log2",
+ * "records_uncached", "force_xcc" (x + 1: the probe stage behaves as if every wavefront ran on XCD x), "bin_timing",
+ * "chunk_bytes" (pipeline chunk size), "h2d_piece" (bytes per host-to-device piece), "h2d_chunks" (a large batch in
+ * host memory is polished in this many pipeline chunks, its pieces crossing on a stream of their own), "inline_tries",
+ * "screen_lds_pad", "no_rounds", "force_rounds", "no_early_copy", "no_lds_ws".
  * The library reads two environment variables only: NTEDIT_HIP_DEBUG (diagnostics on stderr) and
  * NTEDIT_HIP_NO_BIND (see ntedit_hip_bind_near_device). */
 int ntedit_hip_set_tuning(ntedit_hip_ctx* ctx, const char* key, uint64_t value);

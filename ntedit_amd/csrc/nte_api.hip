@@ -109,6 +109,7 @@ struct ntedit_hip_ctx
 		u32 screen_lds_pad = 0;  // LDS pad of the direct screening kernel (occupancy experiments)
 		u32 no_rounds = 0, no_early_copy = 0, no_lds_ws = 0;
 		u32 force_rounds = 0;     // event rounds whatever the number of events (tests: small inputs)
+		u32 machine_pieces = 0;   // a round's list in this many pieces, the sweeps of piece i next to pass 1 of piece i + 1 (0 = automatic, 1 = off)
 		u32 probe_parts_log2 = 0; // the probe stage walks every slice 2^n times, one part of it per walk
 		u32 records_uncached = 0; // the screening records in memory the L2 does not keep (experiments)
 		u32 bin_scatter = 0;      // partition kernel: 0 barrier-phased (k_wc_scatter_b), 1 barrier-free (k_wc_scatter)
@@ -438,6 +439,10 @@ bin_records_lost(ntedit_hip_ctx* c, bool* lost)
 }
 
 // geometry of one record chunk: runs of `cap` records, one per (slice, partition workgroup) pair
+#ifndef NTE_MACHINE_PIECES
+#define NTE_MACHINE_PIECES 1
+#endif
+
 struct WcPlan
 {
 	u32 n_wg;
@@ -1326,7 +1331,8 @@ struct PolishRun
 	int plan();
 	int begin_attempt();
 	int launch_screening(int attempt);
-	void launch_wave_pass(MachineArgs a, const u32* list, u32 count);
+	void launch_wave_pass(MachineArgs a, const u32* list, u32 count, hipStream_t stream = nullptr, u32* counter = nullptr, u32 blocks_per_cu = 8);
+	bool wave_pass_in_lds(const MachineArgs& a) const;
 	int extract_events(size_t j, u64* n_ev_out, u64** d_events_out, u32** d_first_out);
 	int machine_setup(u64 n_ev, u64* d_events, u32* d_first, MachineArgs* out, u64* blocks_out, size_t* dyn_lds_out);
 	int run_chunk_events(size_t j);
@@ -1568,15 +1574,22 @@ PolishRun::launch_screening(int attempt)
 }
 
 // the wavefront-per-event kernel over a list of events of the current chunk
+// (stream / counter: a launch that runs NEXT TO a thread-per-event launch has a stream and a work counter of its own)
 void
-PolishRun::launch_wave_pass(MachineArgs a, const u32* list, u32 count)
+PolishRun::launch_wave_pass(MachineArgs a, const u32* list, u32 count, hipStream_t stream, u32* counter, u32 blocks_per_cu)
 {
+	if (!stream) {
+		stream = sB;
+	}
+	if (counter) {
+		a.work_counter = counter;
+	}
 	a.defer = 0;
 	a.ev_list = list;
 	a.n_events = count;
 	const u64 per_block = (u64)MACHINE_TPB / (u64)machine_wave_group();
 	const u64 want2 = ((u64)count + per_block - 1) / per_block;
-	const u64 cap2 = (u64)c->cu_count * 8;
+	const u64 cap2 = (u64)c->cu_count * blocks_per_cu;
 	const u64 b2 = want2 < cap2 ? want2 : cap2;
 	// the wave kernel runs few events per block: window and workspace both fit in LDS
 	size_t dyn2 = a.win_in_lds ? (size_t)a.win_bytes * per_block : 0;
@@ -1590,8 +1603,21 @@ PolishRun::launch_wave_pass(MachineArgs a, const u32* list, u32 count)
 		a.lds_slab = (u32)slab;
 		dyn2 = (size_t)(win_area + slab * per_block);
 	}
-	(void)hipMemsetAsync(a.work_counter, 0, 4, sB);
-	launch_k_machine_wave((unsigned)b2, dyn2, sB, a);
+	(void)hipMemsetAsync(a.work_counter, 0, 4, stream);
+	launch_k_machine_wave((unsigned)b2, dyn2, stream, a);
+}
+
+// the wave kernel keeps window AND workspace of its events in LDS (so it shares no per-worker slab of global
+// memory with a thread-per-event launch that runs at the same time)
+bool
+PolishRun::wave_pass_in_lds(const MachineArgs& a) const
+{
+	const u64 per_block = (u64)MACHINE_TPB / (u64)machine_wave_group();
+	const u64 Wn = a.p.node_window;
+	const u64 w16 = (Wn + 15) & ~15ull;
+	const u64 slab = Wn * 16 + w16 * 4 + w16 * 2 + w16 + w16;
+	const u64 win_area = ((u64)a.win_bytes * per_block + 15) & ~15ull;
+	return win_area + slab * per_block <= 40 * 1024 && !c->tune.no_lds_ws;
 }
 
 // stream B, chunk j, as soon as its screening is done: absent bitmap -> ordered event list (count, single-workgroup
@@ -1781,10 +1807,95 @@ PolishRun::run_chunk_events(size_t j)
 	HIP_TRY(c, hipEventRecord(c->ev[3], sB));
 	u32 n_def = 0;
 	float p2_ms = 0.f;
+	// A round in pieces: pass 1 (thread per event) of piece i + 1 runs NEXT TO the sweeps (wavefront per event) of
+	// piece i, on two streams, each launch limited to half of a CU's wavefront slots.  Both kernels are bound by the
+	// latency of dependent loads, not by the slots they hold (experiment 15), so the pair takes about as
+	// long as the slower of the two.  The events of a round are independent of each other (that is what makes them
+	// a round); the launches share the arena and the deferred list, both append-only, and nothing else: the sweep
+	// launch has its own work counter and keeps its workspaces in LDS.
+	auto run_round_pieces = [&](const u32* list, u32 count, u32 pieces, bool first_round) -> int {
+		if (!c->stream3) {
+			HIP_TRY(c, hipStreamCreate(&c->stream3));
+		}
+		hipStream_t sC = c->stream3;
+		u32* wc2 = (u32*)((char*)c->counters.p + 72);
+		HIP_TRY(c, hipMemsetAsync(d_ndef, 0, 4, sB));
+		HIP_TRY(c, hipEventRecord(c->ev[5], sB));
+		u32 nd_done = 0; // deferred events handed to a sweep launch so far
+		u32 h_tail[4] = { 0, 0, 0, 0 };
+		for (u32 i = 0; i < pieces && status == 0; i++) {
+			const u32 b0 = (u32)((u64)count * i / pieces), b1 = (u32)((u64)count * (i + 1) / pieces);
+			if (b1 > b0) {
+				MachineArgs ra = a;
+				ra.ev_list = list + b0;
+				ra.n_events = b1 - b0;
+				HIP_TRY(c, hipMemsetAsync(ra.work_counter, 0, 4, sB));
+				const u64 want = ((u64)(b1 - b0) + MACHINE_TPB - 1) / MACHINE_TPB;
+				const u64 cap = i == 0 ? blocks : (u64)c->cu_count * 2; // (piece 0 has the chip to itself)
+				launch_k_machine_thread((unsigned)(want < cap ? want : cap), dyn_lds, sB, ra);
+				HIP_TRY(c, hipGetLastError());
+			}
+			HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+			HIP_TRY(c, hipStreamSynchronize(sB));
+			status = h_tail[2];
+			const u32 nd = h_tail[3];
+			if (status != 0) {
+				break;
+			}
+			const bool last = i + 1 == pieces;
+			if (last) {
+				// every sweep launch so far has to be over before the early copy below may read the arena
+				HIP_TRY(c, hipStreamSynchronize(sC));
+				HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+				HIP_TRY(c, hipStreamSynchronize(sB));
+				status = h_tail[2];
+				if (status != 0) {
+					break;
+				}
+				if (first_round && nd > 0 && n_ch == 1 && !c->tune.no_early_copy) {
+					// everything written so far is final (the last sweep launch only appends chunks)
+					early_chunks = h_tail[0] < arena_chunks ? h_tail[0] : arena_chunks;
+					const u64 room = early_chunks + (u64)nd * 3 + 4096;
+					int prc = pin_take(c, room * CHUNK_ITEMS * sizeof(Item) + 16, &early);
+					if (prc) {
+						return prc;
+					}
+					if (early_chunks) {
+						HIP_TRY(c, hipMemcpyAsync(early.p, c->arena.p, early_chunks * CHUNK_ITEMS * sizeof(Item), hipMemcpyDeviceToHost, sA));
+					}
+				}
+			}
+			if (nd > nd_done) {
+				// (the last one alone on the chip, on stream B; the others next to the following piece's pass 1)
+				launch_wave_pass(a, (const u32*)c->deferred.p + nd_done, nd - nd_done, last ? sB : sC, wc2, last ? 8 : 2);
+				HIP_TRY(c, hipGetLastError());
+				nd_done = nd;
+			}
+		}
+		HIP_TRY(c, hipStreamSynchronize(sC));
+		HIP_TRY(c, hipEventRecord(c->ev[2], sB));
+		HIP_TRY(c, hipMemcpyAsync(h_tail, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+		HIP_TRY(c, hipStreamSynchronize(sB));
+		status = h_tail[2];
+		n_def += nd_done;
+		float t = 0.f;
+		(void)hipEventElapsedTime(&t, c->ev[5], c->ev[2]);
+		p2_ms += t; // (here: the whole round)
+		return 0;
+	};
 	// one round = pass 1 over a list of events (indel sweeps postponed), pass 2 over the postponed ones
 	auto run_round = [&](const u32* list, u32 count, bool first_round) -> int {
 		if (count == 0) {
 			return 0;
+		}
+		{
+			u32 pieces = c->tune.machine_pieces;
+			if (pieces == 0) {
+				pieces = count >= c->cu_count * 4096u ? NTE_MACHINE_PIECES : 1;
+			}
+			if (pieces > 1 && list && count >= pieces && a.win_in_lds && wave_pass_in_lds(a)) {
+				return run_round_pieces(list, count, pieces, first_round);
+			}
 		}
 		MachineArgs ra = a;
 		ra.ev_list = list;
@@ -2557,6 +2668,8 @@ ntedit_hip_set_tuning(ntedit_hip_ctx* c, const char* key, uint64_t value)
 		t.screen_lds_pad = (u32)value;
 	} else if (k == "force_rounds") {
 		t.force_rounds = (u32)value;
+	} else if (k == "machine_pieces") {
+		t.machine_pieces = (u32)value;
 	} else if (k == "no_rounds") {
 		t.no_rounds = (u32)value;
 	} else if (k == "no_early_copy") {

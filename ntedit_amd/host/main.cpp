@@ -27,6 +27,7 @@
 #include <ctime>
 #include <getopt.h>
 #include <sstream>
+#include <memory>
 #include <string>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -576,8 +577,12 @@ main(int argc, char** argv)
 			mine[i] = best == shard_i;
 		}
 	}
-	nte_host::FastaReader reader(draft.c_str());
-	if (!reader.ok()) {
+	// (the streaming reader and its inflate thread only when the mapped reader does not serve the run)
+	std::unique_ptr<nte_host::FastaReader> reader_p;
+	if (!fmap.ok()) {
+		reader_p.reset(new nte_host::FastaReader(draft.c_str()));
+	}
+	if (reader_p && !reader_p->ok()) {
 		fprintf(stderr, PROGRAM ": error: `%s': cannot open\n", draft.c_str());
 		fatal();
 	}
@@ -713,7 +718,7 @@ main(int argc, char** argv)
 		for (;;) {
 			Batch& b = w->b;
 			const size_t before = b.blob.size();
-			if (!reader.next(hdr, b.blob)) {
+			if (!reader_p->next(hdr, b.blob)) {
 				break;
 			}
 			n_contigs++;
@@ -841,9 +846,9 @@ main(int argc, char** argv)
 		fprintf(stderr, PROGRAM ": error: cannot write `%s.index.tsv'\n", prefix.c_str());
 		exit(EXIT_FAILURE);
 	}
-	if (reader.io_error()) {
+	if (reader_p && reader_p->io_error()) {
 		// a corrupt / truncated input must not pass for a (shorter) genome
-		fprintf(stderr, PROGRAM ": error: `%s': %s -- the outputs are incomplete\n", draft.c_str(), reader.io_error_text().c_str());
+		fprintf(stderr, PROGRAM ": error: `%s': %s -- the outputs are incomplete\n", draft.c_str(), reader_p->io_error_text().c_str());
 		fflush(nullptr);
 		_exit(EXIT_FAILURE);
 	}

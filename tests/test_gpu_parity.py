@@ -33,13 +33,16 @@ def _load_filters(pol, case):
         pol.load_filter_file(case["rep"], 1)
 
 
-def _fresh(pol_cls=None, force_rounds=True):
+def _fresh(pol_cls=None, force_rounds=True, pieces=0):
     """a polisher for the small cases of this file: the event rounds (which the library only uses from ~2 M events of a
     batch on) are forced, so that their selection / verification kernels see every configuration"""
     import ntedit_amd
     pol = ntedit_amd.Polisher(0)
     if force_rounds:
         pol.set_tuning("force_rounds", 1)
+    if pieces:
+        # a round in pieces: the sweeps of piece i run next to pass 1 of piece i + 1 (two streams)
+        pol.set_tuning("machine_pieces", pieces)
     return pol
 
 
@@ -49,7 +52,8 @@ def test_polish_matches_oracle(tmp_path, ci, oracle_build):
     case = H.make_case(str(tmp_path), 1000 + ci, **case_kw)
     hp = H.default_params(**par_kw)
     H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), case["rep"])
-    pol = _fresh(force_rounds=ci % 2 == 0)  # (both ways of running the events: in rounds, all at once)
+    # (both ways of running the events: in rounds, all at once; every other round run in 3 pieces)
+    pol = _fresh(force_rounds=ci % 2 == 0, pieces=3 if ci % 4 == 0 else 0)
     try:
         _load_filters(pol, case)
         pol.set_params(_hip_params(**par_kw))

@@ -132,6 +132,9 @@ def main():
                         cmd += ["--tune", "bin_scatter=1"]
                 if rng.random() < 0.5:
                     cmd += ["--tune", "force_rounds=1"]  # (the event rounds, which small batches do not use by themselves)
+                    if rng.random() < 0.6:
+                        # a round in pieces: sweeps of piece i next to pass 1 of piece i + 1
+                        cmd += ["--tune", "machine_pieces=%d" % int(rng.choice([2, 3, 5]))]
                 if "start_grid" in par_kw:
                     cmd += ["--start-grid", str(par_kw["start_grid"])]
                 if "event_budget" in par_kw:

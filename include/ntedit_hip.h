@@ -355,7 +355,8 @@ void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
  * "records_uncached", "force_xcc" (x + 1: the probe stage behaves as if every wavefront ran on XCD x), "bin_timing",
  * "chunk_bytes" (pipeline chunk size), "h2d_piece" (bytes per host-to-device piece), "h2d_chunks" (a large batch in
  * host memory is polished in this many pipeline chunks, its pieces crossing on a stream of their own), "inline_tries",
- * "screen_lds_pad", "no_rounds", "force_rounds", "no_early_copy", "no_lds_ws".
+ * "screen_lds_pad", "no_rounds", "force_rounds", "machine_pieces" (an event round in this many pieces, the sweep launch of
+ * piece i next to the thread-per-event launch of piece i + 1; 0 / 1 = one piece), "no_early_copy", "no_lds_ws".
  * The library reads two environment variables only: NTEDIT_HIP_DEBUG (diagnostics on stderr) and
  * NTEDIT_HIP_NO_BIND (see ntedit_hip_bind_near_device). */
 int ntedit_hip_set_tuning(ntedit_hip_ctx* ctx, const char* key, uint64_t value);

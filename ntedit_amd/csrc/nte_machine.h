@@ -44,16 +44,7 @@ extern WorkCounters g_wc;
 __device__ unsigned long long g_prof[24];
 #endif
 #if defined(NTE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-#define NTE_PROF_DECL                                                     \
-	do {                                                                  \
-		prof_t = __builtin_amdgcn_s_memtime();                            \
-		for (int i_ = 0; i_ < 8; i_++) {                                  \
-			prof_acc[i_] = 0;                                             \
-		}                                                                 \
-		for (int i_ = 0; i_ < 4; i_++) {                                  \
-			prof_cnt[i_] = 0;                                             \
-		}                                                                 \
-	} while (0)
+#define NTE_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, prof_cnt[4] = { 0, 0, 0, 0 }
 #define NTE_PROF_COUNT(slot) (prof_cnt[slot]++)
 #define NTE_PROF(slot)                                                    \
 	do {                                                                  \
@@ -187,12 +178,7 @@ struct Machine
 	bool la_win;      // the character window is still the one the look-ahead was hashed from (the stride needs it)
 #if defined(NTE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 	unsigned long long prof_sub_t = 0, prof_sub[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-	unsigned long long prof_t = 0, prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, prof_cnt[4] = { 0, 0, 0, 0 };
 #endif
-	// state of run()'s main loop between two positions (begin / step / end)
-	u8 r_char_in, r_char_out;
-	bool r_first;
-	u32 r_steps;
 
 	NTE_HD
 	Machine(const EventEnv& env)
@@ -2133,24 +2119,9 @@ struct Machine
 		NTE_PROF_SUB(3);
 	}
 
-	// run one event that starts (clean) with its k-mer head at local position start.
-	// In three parts -- begin(), step() once per position of the walk, end() -- so that a launch with one event per
-	// LANE can hand a lane its next event as soon as its walk ends instead of when the longest walk of the wavefront
-	// does (nte_machine_kernel.inc); run() is the three in a row.
+	// run one event that starts (clean) with its k-mer head at local position start
 	NTE_HD void
 	run(u32 start, u32& cover_end)
-	{
-		if (!begin(start, cover_end)) {
-			return;
-		}
-		while (step(cover_end)) {
-		}
-		end();
-	}
-
-	// false: the event is over before its walk began (cover_end / flags say how)
-	NTE_HD bool
-	begin(u32 start, u32& cover_end)
 	{
 		h_seq_i = start;
 		t_seq_i = start + p.k - 1;
@@ -2196,12 +2167,12 @@ struct Machine
 			u8 code = char_code(e.seq[start + i - 1]);
 			hs.rh = srol1(hs.rh) ^ e.tab[TAB_R + code];
 		}
-		r_char_in = e.seq[t_seq_i];
-		r_char_out = 0;
+		u8 char_in = e.seq[t_seq_i];
+		u8 char_out = 0;
 
 		if (p.debug_stop == 1) {
 			cover_end = e.len;
-			return false;
+			return;
 		}
 		if ((u64)start + p.k == e.len) {
 			// findFirstAcceptedKmer stops at i + k < size (ntedit.cpp:527): the reference never
@@ -2221,174 +2192,163 @@ struct Machine
 			if (!earlier) {
 				flags |= EV_TERMINAL;
 				cover_end = e.len;
-				return false;
+				return;
 			}
 		}
-		r_first = true;
-		r_steps = 0;
+		bool first = true;
+		u32 steps = 0;
 		NTE_PROF_DECL;
-		return true;
-	}
-
-	// one position of the walk; false: the walk is over (cover_end / flags say how), end() follows
-	NTE_HD bool
-	step(u32& cover_end)
-	{
-		NTE_PROF(r_first ? 0 : 5); // 0 = seeding, 5 = loop overhead
-		if (p.event_budget && ++r_steps > p.event_budget && cur_chunk != NONE32) {
-			// A run that does not come back to a clean state for this long is (almost
-			// always) one the serial order will discard: park it.  The host re-runs it
-			// without a budget if it turns out to be applied.
-			flags |= EV_UNFINISHED;
-			cover_end = e.len;
-			return false;
-		}
-		if ((u64)h_seq_i + p.k - 1 >= e.len) {
-			flags |= EV_TERMINAL;
-			cover_end = e.len;
-			return false;
-		}
-		if (flags & (EV_OVERFLOW | EV_ARENA_FULL | EV_DEFERRED)) {
-			cover_end = e.len;
-			return false;
-		}
-		bool missing;
-		if (is_clean()) {
-			u64 g = e.gbase + h_seq_i;
-			if (!r_first && (!bit_absent(e.bitmap, g) || is_event_start(e.bitmap, g, p.start_grid))) {
-				cover_end = h_seq_i;
-				return false;
-			}
-			missing = true; // clean state: the screening bitmap already answered
-		} else {
-			if (p.snv) {
-				missing = true;
-			} else {
-				if (la_i >= la_n && !la_off) {
-					build_lookahead();
-				}
-				if (la_i < la_n) {
-					missing = !((la_mask >> la_i) & 1);
-				} else {
-					missing = screen_absent(hs);
-				}
-			}
-		}
-		const bool was_first = r_first;
-		NTE_PROF(1); // presence of the k-mer at the cursor (look-ahead included)
-		NTE_PROF_COUNT(0);
-		r_first = false;
-		if (missing) {
-			NTE_PROF_COUNT(1);
-			changed_seq = false;
-			process_missing(r_char_in);
-			NTE_PROF(was_first ? 2 : 3); // first / later failing positions
-			la_win = false; // (the failing position filled the window for itself)
-			if (changed_seq) {
-				la_n = la_i = 0; // the sequence has changed: look ahead afresh
-				la_off = false;
-			}
-			// (an error nothing fixes fails at every k-mer that covers it: the k-mers ahead are the same ones)
-		}
-		if (p.debug_stop >= 2 && p.debug_stop < 8) {
-			cover_end = e.len;
-			return false;
-		}
-		if (p.debug_stop >= 8 && was_first) {
-			// 8: keep only events whose first position made an edit; 16: only the others
-			const bool edited = last_sub_pos >= 0 || rope_touched;
-			if ((p.debug_stop == 8 && !edited) || (p.debug_stop == 16 && edited)) {
+		while (true) {
+			NTE_PROF(first ? 0 : 5); // 0 = seeding, 5 = loop overhead
+			if (p.event_budget && ++steps > p.event_budget && cur_chunk != NONE32) {
+				// A run that does not come back to a clean state for this long is (almost
+				// always) one the serial order will discard: park it.  The host re-runs it
+				// without a budget if it turns out to be applied.
+				flags |= EV_UNFINISHED;
 				cover_end = e.len;
-				return false;
-			}
-		}
-		// Behind an edit the next k-1 k-mers hold the new base(s); they were probed together (look-ahead)
-		// and, as a rule, are all there: the reference rolls through them one position at a time doing
-		// nothing.  That stretch of the walk is taken in one stride: the cursors are rolled without reading
-		// characters (increment() only: rope nodes, no draft bytes), as long as the next position is
-		// looked-ahead, present, inside the contig and still dirty -- where the machine would be clean the
-		// main loop has to consult the screening bitmap itself -- and the hash is rolled from the window codes
-		// the look-ahead was hashed from.
-		NTE_PROF_SUB(7);
-		if (!missing && la_i < la_n && la_win && !is_clean()) {
-			u32 J = 0;
-			u32 room = 0xFFFFFFFFu;
-			if (p.event_budget) {
-				room = r_steps < p.event_budget ? p.event_budget - r_steps : 0;
-			}
-			// (the nodes under the two cursors are kept in registers: a roll inside a node costs no rope access)
-			Node nh = nget(h_node), nt = nget(t_node);
-			u32 hs2 = h_seq_i, ts2 = t_seq_i, hn2 = h_node, tn2 = t_node;
-			while (la_i + J + 1 < la_n && ((la_mask >> (la_i + J + 1)) & 1) && J < room) {
-				// one roll of the cursors (roll(), ntedit.cpp:1216-1247) on copies
-				u32 hs3 = hs2, ts3 = ts2, hn3 = hn2, tn3 = tn2;
-				Node nh3 = nh, nt3 = nt;
-				if (hs3 >= e.len || hn3 >= nsize) {
-					break;
-				}
-				increment_cached(hs3, hn3, nh3);
-				if (ts3 >= e.len || tn3 >= nsize) {
-					break;
-				}
-				increment_cached(ts3, tn3, nt3);
-				if (ts3 >= e.len || tn3 >= nsize || (u64)hs3 + p.k - 1 >= e.len) {
-					break;
-				}
-				if (clean_at(hs3, ts3, hn3, tn3, nt3)) {
-					break; // where the machine would be clean the main loop consults the screening bitmap itself
-				}
-				hs2 = hs3;
-				ts2 = ts3;
-				hn2 = hn3;
-				tn2 = tn3;
-				nh = nh3;
-				nt = nt3;
-				J++;
-			}
-			if (J) {
-				h_seq_i = hs2;
-				t_seq_i = ts2;
-				h_node = hn2;
-				t_node = tn2;
-				for (u32 q = 0; q < J; q++) {
-					hash_roll(hs, e.tab, win_o(la_i + q), win_i(la_i + q));
-				}
-				la_i += J;
-				r_steps += J;
-				r_char_in = get_character(t_seq_i, nget(t_node));
-			}
-		}
-		NTE_PROF_SUB(5); // stride
-		// advance; skip over k-mers containing a non-accepted base (ntedit.cpp:2119-2138)
-		bool ended = false;
-		int64_t target = -1;
-		do {
-			if (roll(h_seq_i, t_seq_i, h_node, t_node, r_char_out, r_char_in)) {
-				la_i++;
-				if (char_code(r_char_in) == CODE_BAD) {
-					target = (int64_t)t_seq_i + (int64_t)p.k;
-				}
-				roll_hash(hs, r_char_out, r_char_in);
-			} else {
-				ended = true;
 				break;
 			}
-		} while (target >= 0 && (int64_t)t_seq_i != target);
-		if (ended) {
-			flags |= EV_TERMINAL;
-			cover_end = e.len;
-			return false;
+			if ((u64)h_seq_i + p.k - 1 >= e.len) {
+				flags |= EV_TERMINAL;
+				cover_end = e.len;
+				break;
+			}
+			if (flags & (EV_OVERFLOW | EV_ARENA_FULL | EV_DEFERRED)) {
+				cover_end = e.len;
+				break;
+			}
+			bool missing;
+			if (is_clean()) {
+				u64 g = e.gbase + h_seq_i;
+				if (!first && (!bit_absent(e.bitmap, g) || is_event_start(e.bitmap, g, p.start_grid))) {
+					cover_end = h_seq_i;
+					break;
+				}
+				missing = true; // clean state: the screening bitmap already answered
+			} else {
+				if (p.snv) {
+					missing = true;
+				} else {
+					if (la_i >= la_n && !la_off) {
+						build_lookahead();
+					}
+					if (la_i < la_n) {
+						missing = !((la_mask >> la_i) & 1);
+					} else {
+						missing = screen_absent(hs);
+					}
+				}
+			}
+			const bool was_first = first;
+			NTE_PROF(1); // presence of the k-mer at the cursor (look-ahead included)
+			NTE_PROF_COUNT(0);
+			first = false;
+			if (missing) {
+				NTE_PROF_COUNT(1);
+				changed_seq = false;
+				process_missing(char_in);
+				NTE_PROF(was_first ? 2 : 3); // first / later failing positions
+				la_win = false; // (the failing position filled the window for itself)
+				if (changed_seq) {
+					la_n = la_i = 0; // the sequence has changed: look ahead afresh
+					la_off = false;
+				}
+				// (an error nothing fixes fails at every k-mer that covers it: the k-mers ahead are the same ones)
+			}
+			if (p.debug_stop >= 2 && p.debug_stop < 8) {
+				cover_end = e.len;
+				break;
+			}
+			if (p.debug_stop >= 8 && was_first) {
+				// 8: keep only events whose first position made an edit; 16: only the others
+				const bool edited = last_sub_pos >= 0 || rope_touched;
+				if ((p.debug_stop == 8 && !edited) || (p.debug_stop == 16 && edited)) {
+					cover_end = e.len;
+					break;
+				}
+			}
+			// Behind an edit the next k-1 k-mers hold the new base(s); they were probed together (look-ahead)
+			// and, as a rule, are all there: the reference rolls through them one position at a time doing
+			// nothing.  That stretch of the walk is taken in one stride: the cursors are rolled without reading
+			// characters (increment() only: rope nodes, no draft bytes), as long as the next position is
+			// looked-ahead, present, inside the contig and still dirty -- where the machine would be clean the
+			// main loop has to consult the screening bitmap itself -- and the hash is rolled from the window codes
+			// the look-ahead was hashed from.
+			NTE_PROF_SUB(7);
+			if (!missing && la_i < la_n && la_win && !is_clean()) {
+				u32 J = 0;
+				u32 room = 0xFFFFFFFFu;
+				if (p.event_budget) {
+					room = steps < p.event_budget ? p.event_budget - steps : 0;
+				}
+				// (the nodes under the two cursors are kept in registers: a roll inside a node costs no rope access)
+				Node nh = nget(h_node), nt = nget(t_node);
+				u32 hs2 = h_seq_i, ts2 = t_seq_i, hn2 = h_node, tn2 = t_node;
+				while (la_i + J + 1 < la_n && ((la_mask >> (la_i + J + 1)) & 1) && J < room) {
+					// one roll of the cursors (roll(), ntedit.cpp:1216-1247) on copies
+					u32 hs3 = hs2, ts3 = ts2, hn3 = hn2, tn3 = tn2;
+					Node nh3 = nh, nt3 = nt;
+					if (hs3 >= e.len || hn3 >= nsize) {
+						break;
+					}
+					increment_cached(hs3, hn3, nh3);
+					if (ts3 >= e.len || tn3 >= nsize) {
+						break;
+					}
+					increment_cached(ts3, tn3, nt3);
+					if (ts3 >= e.len || tn3 >= nsize || (u64)hs3 + p.k - 1 >= e.len) {
+						break;
+					}
+					if (clean_at(hs3, ts3, hn3, tn3, nt3)) {
+						break; // where the machine would be clean the main loop consults the screening bitmap itself
+					}
+					hs2 = hs3;
+					ts2 = ts3;
+					hn2 = hn3;
+					tn2 = tn3;
+					nh = nh3;
+					nt = nt3;
+					J++;
+				}
+				if (J) {
+					h_seq_i = hs2;
+					t_seq_i = ts2;
+					h_node = hn2;
+					t_node = tn2;
+					for (u32 q = 0; q < J; q++) {
+						hash_roll(hs, e.tab, win_o(la_i + q), win_i(la_i + q));
+					}
+					la_i += J;
+					steps += J;
+					char_in = get_character(t_seq_i, nget(t_node));
+				}
+			}
+			NTE_PROF_SUB(5); // stride
+			// advance; skip over k-mers containing a non-accepted base (ntedit.cpp:2119-2138)
+			bool ended = false;
+			int64_t target = -1;
+			do {
+				if (roll(h_seq_i, t_seq_i, h_node, t_node, char_out, char_in)) {
+					la_i++;
+					if (char_code(char_in) == CODE_BAD) {
+						target = (int64_t)t_seq_i + (int64_t)p.k;
+					}
+					roll_hash(hs, char_out, char_in);
+				} else {
+					ended = true;
+					break;
+				}
+			} while (target >= 0 && (int64_t)t_seq_i != target);
+			if (ended) {
+				flags |= EV_TERMINAL;
+				cover_end = e.len;
+				break;
+			}
+			NTE_PROF_SUB(6); // roll
+			NTE_PROF(4); // advance
+			housekeeping();
+			NTE_PROF(6);
 		}
-		NTE_PROF_SUB(6); // roll
-		NTE_PROF(4); // advance
-		housekeeping();
-		NTE_PROF(6);
-		return true;
-	}
-
-	NTE_HD void
-	end()
-	{
 		NTE_PROF(5);
 
 		// stream out what is left of the rope (only if an indel touched it)

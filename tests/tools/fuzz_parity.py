@@ -85,6 +85,7 @@ def main():
     t_end = time.time() + args.minutes * 60 if args.minutes else None
     bad = 0
     it = 0
+    t_start = time.time()
     while it < args.iters or (t_end and time.time() < t_end):
         if t_end and time.time() >= t_end:
             break
@@ -139,7 +140,9 @@ def main():
                     cmd += ["--start-grid", str(par_kw["start_grid"])]
                 if "event_budget" in par_kw:
                     cmd += ["--event-budget", str(par_kw["event_budget"])]
-                r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+                if os.environ.get("FUZZ_TRACE"):  # one line per case (which one hangs or crawls)
+                    print("[%d] seed %d t=%.0fs: %s" % (it, seed, time.time() - t_start, " ".join(cmd[1:])), file=sys.stderr, flush=True)
+                r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=int(os.environ.get("FUZZ_CASE_TIMEOUT", "600")))
                 if r.returncode != 0:
                     why = "ntedit exit %d: %s" % (r.returncode, r.stderr[-300:])
             else:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The thread-per-event launch with merged walks: parity of the small cases, a fuzz run, then the 3 Gbp step, the shard sizes
+# (written for the merged-walks build of commit 818b670) parity of the small cases, a fuzz run, then the 3 Gbp step, the shard sizes
 # of a strong-scaling run and configs[2].   tools/gpu_merged.sh
 cd "$GRAFT_REPO_ROOT" || exit 1
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "test_polish_matches_oracle" 2>&1 | tail -3

@@ -173,7 +173,7 @@ typedef struct ntedit_hip_stats
 	uint64_t events_applied; /* events that survive the serial-order filter  */
 	uint64_t substitutions, insertions, deletions; /* rope/record counts     */
 	float ms_screen;         /* HIP-event time of the screening launches (sum) */
-	float ms_extract;        /* (folded into ms_machine's stream; 0)          */
+	float ms_extract;        /* the run-map kernel (k_assess: -s 1, counting filters); 0 when it does not run */
 	float ms_machine;        /* event machine launches (sum); overlaps screening when pipelined */
 	float ms_total;          /* first kernel start -> edit records in host memory */
 	uint32_t screen_launches; /* launches of the dominant screening kernel in this batch: k_bin_probe (binned

@@ -89,6 +89,8 @@ struct ntedit_hip_ctx
 	std::string err;
 	float last_ms = 0.f;
 	hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	hipEvent_t ev_assess[2] = { nullptr, nullptr };
+	DevBuf runmap; // the absent bitmap minus the positions that cannot do anything (k_assess)
 	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters, deferred;
 	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps, ws_win;
 	DevBuf offs, lens;
@@ -106,6 +108,10 @@ struct ntedit_hip_ctx
 		u64 chunk_bytes = 0;     // pipeline chunk size (tests: many chunks)
 		u64 h2d_piece = ~0ULL;   // bytes per host-to-device piece (~0: default)
 		u32 inline_tries = ~0u;  // candidates of an indel sweep the deferring launch tries itself (~0: default)
+		u32 assess = ~0u;        // k_assess before the event machine: 0 never, 1 always, ~0: with -s 1 and with counting filters
+		u32 machine_cfg = ~0u;   // 0: always the general instantiation of the machine kernels (~0: the most specific one)
+		u32 lanes = ~0u;         // DevParams::lanes (~0: default)
+		u32 defer_run = ~0u;     // DevParams::defer_run (~0: default)
 		u32 screen_lds_pad = 0;  // LDS pad of the direct screening kernel (occupancy experiments)
 		u32 no_rounds = 0, no_early_copy = 0, no_lds_ws = 0;
 		u32 force_rounds = 0;     // event rounds whatever the number of events (tests: small inputs)
@@ -285,6 +291,12 @@ refresh_params(ntedit_hip_ctx* c)
 #endif
 	if (c->tune.inline_tries != ~0u) { // tuning / tests (any value gives the same results)
 		c->dp.inline_tries = c->tune.inline_tries;
+	}
+	if (c->tune.lanes != ~0u) {
+		c->dp.lanes = c->tune.lanes;
+	}
+	if (c->tune.defer_run != ~0u) {
+		c->dp.defer_run = c->tune.defer_run;
 	}
 	if (!c->d_tab) {
 		HIP_TRY(c, hipMalloc((void**)&c->d_tab, TAB_WORDS * sizeof(u64)));
@@ -797,6 +809,12 @@ ntedit_hip_create(int device, ntedit_hip_ctx** out)
 			return NTEDIT_E_DEVICE;
 		}
 	}
+	for (auto& e : c->ev_assess) {
+		if (hipEventCreate(&e) != hipSuccess) {
+			delete c;
+			return NTEDIT_E_DEVICE;
+		}
+	}
 	{
 		std::lock_guard<std::mutex> lk(g_live_mu);
 		g_live_ctx.push_back(c);
@@ -829,7 +847,7 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 	}
 	DevBuf* bufs[] = { &c->seq,      &c->bitmap,   &c->block_counts, &c->block_offsets, &c->events,
 		               &c->first_chunk, &c->arena, &c->counters, &c->deferred,     &c->ws_nodes,      &c->ws_ov_pos,
-		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->bin_records[0], &c->bin_records[1], &c->bin_fill[0], &c->bin_fill[1], &c->bin_ctl[0], &c->bin_ctl[1], &c->bin_ovf[0], &c->bin_ovf[1], &c->bin_lost, &c->ev_cover, &c->ev_before, &c->ev_flags, &c->ev_list, &c->ev_bmax,       &c->offs,          &c->lens };
+		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->runmap, &c->bin_records[0], &c->bin_records[1], &c->bin_fill[0], &c->bin_fill[1], &c->bin_ctl[0], &c->bin_ctl[1], &c->bin_ovf[0], &c->bin_ovf[1], &c->bin_lost, &c->ev_cover, &c->ev_before, &c->ev_flags, &c->ev_list, &c->ev_bmax,       &c->offs,          &c->lens };
 	for (DevBuf* b : bufs) {
 		release(*b);
 	}
@@ -841,6 +859,11 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 		(void)hipFree(c->d_tab);
 	}
 	for (auto& e : c->ev) {
+		if (e) {
+			(void)hipEventDestroy(e);
+		}
+	}
+	for (auto& e : c->ev_assess) {
 		if (e) {
 			(void)hipEventDestroy(e);
 		}
@@ -1260,6 +1283,8 @@ ntedit_hip_screen(ntedit_hip_ctx* c, const char* bases, uint64_t n, int on_devic
 // finish()            timings
 namespace {
 
+constexpr unsigned NTE_RESOLVE_ROUNDS = 6; // rounds of one-parked-event-per-contig re-runs before the re-runs are widened (collect())
+
 struct PolishRun
 {
 	// the call
@@ -1285,6 +1310,9 @@ struct PolishRun
 	u64 n_words = 0;
 	const u8* d_seq = nullptr;
 	u64* d_bitmap = nullptr;
+	u64* d_runmap = nullptr;  // = d_bitmap unless k_assess runs
+	bool use_assess = false;
+	float ms_assess = 0.f;
 	hipStream_t sA = nullptr; // screening
 	hipStream_t sB = nullptr; // event extraction + event machine (and H2D pieces while the screening runs)
 	u32 grid = 0;
@@ -1331,6 +1359,7 @@ struct PolishRun
 	int plan();
 	int begin_attempt();
 	int launch_screening(int attempt);
+	int launch_assess(u64 pos_begin, u64 pos_end);
 	void launch_wave_pass(MachineArgs a, const u32* list, u32 count, hipStream_t stream = nullptr, u32* counter = nullptr, u32 blocks_per_cu = 8);
 	bool wave_pass_in_lds(const MachineArgs& a) const;
 	int extract_events(size_t j, u64* n_ev_out, u64** d_events_out, u32** d_first_out);
@@ -1362,6 +1391,7 @@ PolishRun::plan()
 		return rc;
 	}
 	d_bitmap = (u64*)c->bitmap.p;
+	d_runmap = d_bitmap;
 	sA = c->stream;
 	sB = c->stream2;
 	HIP_TRY(c, hipMemcpyAsync(c->offs.p, offsets, (size_t)n_contigs * 8, hipMemcpyHostToDevice, sA));
@@ -1428,6 +1458,15 @@ PolishRun::plan()
 		}
 	}
 	f0 = dev_filter(c->filt[0]);
+	// the run map (nte_assess.hip): where most absent positions cannot do anything -- every position is "absent" with
+	// -s 1, a quarter of them with a counting filter and -p 2 -- they are taken out before the event machine sees them
+	use_assess = n_ch == 1 && (c->tune.assess == 1 || (c->tune.assess == ~0u && (c->dp.snv || c->dp.counting)));
+	if (use_assess) {
+		if ((rc = ensure(c, c->runmap, (n_words + 8) * 8))) {
+			return rc;
+		}
+		d_runmap = (u64*)c->runmap.p;
+	}
 	// with more than one chunk the screening kernel is held to 2 workgroups per CU (its speed
 	// is set by the L2-miss path, not by occupancy) so the machine kernels of the previous
 	// chunk get wave slots, registers and LDS on every CU
@@ -1507,6 +1546,9 @@ PolishRun::launch_screening(int attempt)
 			}
 			h2d_launches++;
 		}
+		if ((rc = launch_assess(0, n))) {
+			return rc;
+		}
 		HIP_TRY(c, hipEventRecord(c->chunk_ev[1], sA));
 	} else if (!pipelined) {
 		c->h2d_piece_bytes = 0;
@@ -1523,7 +1565,7 @@ PolishRun::launch_screening(int attempt)
 		HIP_TRY(c, hipEventRecord(c->chunk_ev[0], sA));
 		rc = launch_screen<false>(c, d_seq, n, f0, d_bitmap, n_words);
 		c->h2d_piece_bytes = 0;
-		if (rc) {
+		if (rc || (rc = launch_assess(0, n))) {
 			return rc;
 		}
 		HIP_TRY(c, hipEventRecord(c->chunk_ev[1], sA));
@@ -1573,6 +1615,34 @@ PolishRun::launch_screening(int attempt)
 	return 0;
 }
 
+// stream A, behind the screening of [pos_begin, pos_end): the run map of those positions
+int
+PolishRun::launch_assess(u64 pos_begin, u64 pos_end)
+{
+	if (!use_assess || pos_end <= pos_begin) {
+		return 0;
+	}
+	AssessArgs a;
+	a.seq = d_seq;
+	a.n_bytes = n;
+	a.bitmap = d_bitmap;
+	a.runmap = d_runmap;
+	a.tabs = c->d_tab;
+	a.p = c->dp;
+	a.bloom = f0;
+	a.rep = c->filt[1].set ? dev_filter(c->filt[1]) : f0;
+	a.pos_begin = pos_begin;
+	a.pos_end = pos_end;
+	const u64 tile = (u64)assess_tile();
+	a.n_tiles = (pos_end - pos_begin + tile - 1) / tile;
+	const u64 cap = (u64)c->cu_count * 32;
+	HIP_TRY(c, hipEventRecord(c->ev_assess[0], sA));
+	launch_k_assess((unsigned)(a.n_tiles < cap ? a.n_tiles : cap), sA, a);
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipEventRecord(c->ev_assess[1], sA));
+	return 0;
+}
+
 // the wavefront-per-event kernel over a list of events of the current chunk
 // (stream / counter: a launch that runs NEXT TO a thread-per-event launch has a stream and a work counter of its own)
 void
@@ -1587,6 +1657,7 @@ PolishRun::launch_wave_pass(MachineArgs a, const u32* list, u32 count, hipStream
 	a.defer = 0;
 	a.ev_list = list;
 	a.n_events = count;
+	a.win_bytes += 64; // (one shared window for the positions of 64 lanes, run_lanes)
 	const u64 per_block = (u64)MACHINE_TPB / (u64)machine_wave_group();
 	const u64 want2 = ((u64)count + per_block - 1) / per_block;
 	const u64 cap2 = (u64)c->cu_count * blocks_per_cu;
@@ -1616,7 +1687,7 @@ PolishRun::wave_pass_in_lds(const MachineArgs& a) const
 	const u64 Wn = a.p.node_window;
 	const u64 w16 = (Wn + 15) & ~15ull;
 	const u64 slab = Wn * 16 + w16 * 4 + w16 * 2 + w16 + w16;
-	const u64 win_area = ((u64)a.win_bytes * per_block + 15) & ~15ull;
+	const u64 win_area = ((u64)(a.win_bytes + 64) * per_block + 15) & ~15ull;
 	return win_area + slab * per_block <= 40 * 1024 && !c->tune.no_lds_ws;
 }
 
@@ -1643,7 +1714,7 @@ PolishRun::extract_events(size_t j, u64* n_ev_out, u64** d_events_out, u32** d_f
 	}
 	HIP_TRY(c, hipMemsetAsync((char*)c->counters.p + 8, 0, 8, sB));
 	hipLaunchKernelGGL(
-	    k_count_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_bitmap, w0, w1, ch.b0, ch.b1, grid_lo, grid,
+	    k_count_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_runmap, w0, w1, ch.b0, ch.b1, grid_lo, grid,
 	    (u32*)c->block_counts.p, d_counters);
 	hipLaunchKernelGGL(
 	    k_scan_counts, dim3(1), dim3(1024), 0, sB, (const u32*)c->block_counts.p, n_sblocks,
@@ -1683,7 +1754,7 @@ PolishRun::extract_events(size_t j, u64* n_ev_out, u64** d_events_out, u32** d_f
 	u64* d_events = (u64*)c->events.p + ev_total;
 	u32* d_first = (u32*)c->first_chunk.p + ev_total;
 	hipLaunchKernelGGL(
-	    k_write_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_bitmap, w0, w1, ch.b0, ch.b1, grid_lo, grid,
+	    k_write_starts, dim3((unsigned)n_sblocks), dim3(ST_TPB), 0, sB, d_runmap, w0, w1, ch.b0, ch.b1, grid_lo, grid,
 	    (const unsigned long long*)c->block_offsets.p, d_events);
 	*n_ev_out = n_ev;
 	*d_events_out = d_events;
@@ -1713,6 +1784,7 @@ PolishRun::machine_setup(u64 n_ev, u64* d_events, u32* d_first, MachineArgs* out
 	a.lens = (const u32*)c->lens.p;
 	a.n_contigs = n_contigs;
 	a.bitmap = d_bitmap;
+	a.runmap = d_runmap;
 	a.events = d_events;
 	a.n_events = n_ev;
 	a.tabs = c->d_tab;
@@ -1728,7 +1800,7 @@ PolishRun::machine_setup(u64 n_ev, u64* d_events, u32* d_first, MachineArgs* out
 	a.win_in_lds = (size_t)a.win_bytes * MACHINE_TPB <= 40 * 1024 ? 1 : 0;
 	a.ws_win = nullptr;
 	if (!a.win_in_lds) {
-		if ((rc = ensure(c, c->ws_win, threads * a.win_bytes))) {
+		if ((rc = ensure(c, c->ws_win, threads * (a.win_bytes + 64)))) { // (+ 64: the wavefront-per-event launch, launch_wave_pass)
 			return rc;
 		}
 		a.ws_win = (u8*)c->ws_win.p;
@@ -1750,6 +1822,7 @@ PolishRun::machine_setup(u64 n_ev, u64* d_events, u32* d_first, MachineArgs* out
 	if (n_ch != 1) {
 		a.p.event_budget = 0; // (parked events are re-run per batch: single-chunk batches only)
 	}
+	a.cfg = c->tune.machine_cfg != ~0u ? c->tune.machine_cfg : machine_cfg_pick(a);
 	*out = a;
 	*blocks_out = blocks;
 	*dyn_lds_out = dyn_lds;
@@ -1900,6 +1973,22 @@ PolishRun::run_chunk_events(size_t j)
 		MachineArgs ra = a;
 		ra.ev_list = list;
 		ra.n_events = count;
+		if (a.p.snv && a.p.lanes && a.p.mode == 0 && !a.p.mask && !use_assess) {
+			// -s 1: every position of every event is assessed, there is nothing a thread-per-event pass could settle
+			// more cheaply -- all events go to the wavefront-per-event launch, 64 positions at a time (run_lanes)
+			HIP_TRY(c, hipEventRecord(c->ev[5], sB));
+			launch_wave_pass(ra, list, count);
+			HIP_TRY(c, hipGetLastError());
+			HIP_TRY(c, hipEventRecord(c->ev[2], sB));
+			u32 h_t[4] = { 0, 0, 0, 0 };
+			HIP_TRY(c, hipMemcpyAsync(h_t, (char*)c->counters.p + 32, 16, hipMemcpyDeviceToHost, sB));
+			HIP_TRY(c, hipStreamSynchronize(sB));
+			status = h_t[2];
+			float t = 0.f;
+			(void)hipEventElapsedTime(&t, c->ev[5], c->ev[2]);
+			p2_ms += t;
+			return 0;
+		}
 		HIP_TRY(c, hipMemsetAsync(d_ndef, 0, 4, sB));
 		HIP_TRY(c, hipMemsetAsync(ra.work_counter, 0, 4, sB));
 		const u64 want = ((u64)count + MACHINE_TPB - 1) / MACHINE_TPB;
@@ -2016,14 +2105,22 @@ PolishRun::run_chunk_events(size_t j)
 		    "machine %.3f ms (sweep launches %.3f ms) arena %u status %u window %u\n",
 		    j + 1, n_ch, ch.c0, ch.c1, (unsigned long long)n_ev, n_A, n_B, n_C,
 		    (unsigned long long)(rounds ? (u64)n32 - n_A - n_B - n_C : 0), n_def, p_all, p2_ms, h_tail[0], status, c->dp.node_window);
-		unsigned long long pr[24];
+		unsigned long long pr[64];
 		machine_wave_profile(pr);
 		if (pr[8]) {
+			fprintf(stderr, "[ntedit_hip] wave-kernel events by duration (log2 cycles: count):");
+			for (int b = 0; b < 32; b++) {
+				if (pr[32 + b]) {
+					fprintf(stderr, " %d:%llu", b, pr[32 + b]);
+				}
+			}
+			fprintf(stderr, "; longest %llu cycles, most positions in one event %llu\n", pr[13], pr[14]);
 			fprintf(stderr, "[ntedit_hip] wave-kernel phase cycles/event (n=%llu): seed %llu presence %llu first-miss %llu later-miss %llu advance %llu loop %llu housekeeping %llu flush %llu; positions/event %.1f failing %.1f\n",
 			    pr[8], pr[0] / pr[8], pr[1] / pr[8], pr[2] / pr[8], pr[3] / pr[8], pr[4] / pr[8], pr[5] / pr[8], pr[6] / pr[8], pr[7] / pr[8],
 			    (double)pr[9] / (double)pr[8], (double)pr[10] / (double)pr[8]);
-			fprintf(stderr, "[ntedit_hip]   inside failing positions: window %llu step-2 %llu substitutions %llu indel sweeps %llu apply %llu; advance: stride %llu roll %llu\n",
-			    pr[16] / pr[8], pr[17] / pr[8], pr[18] / pr[8], pr[20] / pr[8], pr[19] / pr[8], pr[21] / pr[8], pr[22] / pr[8]);
+			fprintf(stderr, "[ntedit_hip]   inside failing positions: window %llu step-2 %llu substitutions (lanes: the lanes' own phases) %llu indel sweeps %llu apply %llu; advance: stride %llu roll %llu; lane batches/event %.2f lanes/batch %.1f\n",
+			    pr[16] / pr[8], pr[17] / pr[8], pr[18] / pr[8], pr[20] / pr[8], pr[19] / pr[8], pr[21] / pr[8], pr[22] / pr[8],
+			    (double)pr[11] / (double)pr[8], pr[11] ? (double)pr[12] / (double)pr[11] : 0.0);
 		}
 	}
 	ev_total += n_ev;
@@ -2079,10 +2176,23 @@ PolishRun::collect(bool* redo)
 		}
 		u64 have_chunks = used_chunks;
 		unsigned rounds = 0;
+		// The walk hands out one parked event per contig and round: the first one the serial order reaches.  That is
+		// the cheapest plan when few events are parked (the ordinary case: a handful per 3 Gbp) or when the first
+		// re-run covers its whole contig (a saturated filter), and a crawl when nearly everything is parked and
+		// every run is short (a tiny budget: one launch per dependency level).  After NTE_RESOLVE_ROUNDS rounds the
+		// re-runs are widened instead: ALL events still parked behind the waiting points at once, with a budget
+		// that grows 16-fold per round (speculation again, bounded by that budget), until none is left.
+		u32 wide_budget = keep_a.p.event_budget ? keep_a.p.event_budget : 1;
 		while (!rerun.empty()) {
+			const bool wide = rounds >= NTE_RESOLVE_ROUNDS;
+			if (wide) {
+				rerun.clear();
+				rs.parked_behind(rerun);
+				wide_budget = wide_budget < (1u << 26) ? wide_budget * 16u : 0u;
+			}
 			HIP_TRY(c, hipMemcpyAsync(c->deferred.p, rerun.data(), rerun.size() * 4, hipMemcpyHostToDevice, sB));
 			MachineArgs ra = keep_a;
-			ra.p.event_budget = 0;
+			ra.p.event_budget = wide ? wide_budget : 0;
 			ra.ev_cover = nullptr; // (the rounds are over)
 			ra.ev_flags = nullptr;
 			launch_wave_pass(ra, (const u32*)c->deferred.p, (u32)rerun.size());
@@ -2120,7 +2230,7 @@ PolishRun::collect(bool* redo)
 			r->arena_items = (size_t)now_chunks * CHUNK_ITEMS;
 			rs.rebind((const Item*)r->arena_buf.p, r->arena_items, (const u32*)r->first_buf.p);
 			rerun.clear();
-			if (!rs.resume(rerun) || ++rounds > 10000000u) {
+			if (!rs.resume(rerun, wide) || ++rounds > 10000000u) {
 				return fail(c, NTEDIT_E_DEVICE, "parked events could not be resolved");
 			}
 		}
@@ -2162,6 +2272,9 @@ PolishRun::finish()
 	r->st.events_skipped = (uint32_t)skipped_total;
 	r->st.ms_machine = ms_machine;
 	r->st.ms_extract = 0.f;
+	if (use_assess) {
+		(void)hipEventElapsedTime(&r->st.ms_extract, c->ev_assess[0], c->ev_assess[1]); // (the run map, k_assess)
+	}
 	HIP_TRY(c, hipEventElapsedTime(&r->st.ms_total, c->ev[0], c->ev[4]));
 	c->last_ms = ms_screen;
 	return 0;
@@ -2663,6 +2776,16 @@ ntedit_hip_set_tuning(ntedit_hip_ctx* c, const char* key, uint64_t value)
 		t.h2d_piece = value;
 	} else if (k == "inline_tries") {
 		t.inline_tries = (u32)value;
+		c->dp_valid = false;
+	} else if (k == "assess") {
+		t.assess = (u32)value;
+	} else if (k == "machine_cfg") {
+		t.machine_cfg = value ? ~0u : 0u; // (only "general" can be forced: a specialised instantiation is wrong for other configurations)
+	} else if (k == "lanes") {
+		t.lanes = (u32)value;
+		c->dp_valid = false;
+	} else if (k == "defer_run") {
+		t.defer_run = (u32)value;
 		c->dp_valid = false;
 	} else if (k == "screen_lds_pad") {
 		t.screen_lds_pad = (u32)value;

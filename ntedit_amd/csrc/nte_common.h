@@ -323,6 +323,10 @@ struct DevParams
 	u32 counting;      // primary filter is a counting filter
 	u32 snv;           // -s 1: every position is re-assessed (ntedit.cpp:1806,1865)
 	u32 min_thr, max_thr; // -p / -q (ntedit.cpp:131-132); only meaningful with a counting filter
+	u32 lanes;         // wavefront-per-event launch: runs of failing positions are assessed one position per lane
+	                   // (0 off, 1 in the clean state, 2 also while the window holds substituted bases; nte_machine.h)
+	u32 defer_run;     // thread-per-event launch: an event whose clean position ends without an edit and whose absent run
+	                   // goes on for at least this many positions is handed to the wavefront-per-event launch (0 = never)
 	u64 mul[MAX_HASHES]; // mul[i] = i ^ (k * MULTISEED), i >= 1
 };
 

@@ -31,6 +31,7 @@ namespace nte {
 struct WorkCounters
 {
 	unsigned long long probes, fast_rolls, slow_rolls, ins_cands, del_cands, sweeps, windows_fast, windows_slow, windows_fail;
+	unsigned long long lane_batches, lane_positions, lane_walked, lane_edits;
 };
 extern WorkCounters g_wc;
 #define NTE_COUNT(f, n) (g_wc.f += (n))
@@ -41,11 +42,12 @@ extern WorkCounters g_wc;
 // Phase timers of the wavefront-per-event kernel (build nte_machine_wave.hip with
 // -DNTE_PROFILE): shader cycles per phase, summed over events into g_prof[].
 #if defined(NTE_PROFILE)
-__device__ unsigned long long g_prof[24];
+static __device__ unsigned long long g_prof[64]; // (one per translation unit: the kernels are compiled per configuration)
 #endif
 #if defined(NTE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-#define NTE_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, prof_cnt[4] = { 0, 0, 0, 0 }
+#define NTE_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_t0 = prof_t, prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
 #define NTE_PROF_COUNT(slot) (prof_cnt[slot]++)
+#define NTE_PROF_ADD(slot, n) (prof_cnt[slot] += (n))
 #define NTE_PROF(slot)                                                    \
 	do {                                                                  \
 		const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
@@ -66,6 +68,12 @@ __device__ unsigned long long g_prof[24];
 				atomicAdd(&g_prof[16 + i_], prof_sub[i_]);                \
 			}                                                             \
 			atomicAdd(&g_prof[8], 1ull);                                  \
+			{                                                             \
+				const unsigned long long dur_ = __builtin_amdgcn_s_memtime() - prof_t0; \
+				atomicAdd(&g_prof[32 + (63 - __builtin_clzll(dur_ | 1ull)) % 32], 1ull); \
+				atomicMax(&g_prof[13], dur_);                             \
+				atomicMax(&g_prof[14], (unsigned long long)prof_cnt[0]);  \
+			}                                                             \
 			for (int i_ = 0; i_ < 4; i_++) {                              \
 				atomicAdd(&g_prof[9 + i_], prof_cnt[i_]);                 \
 			}                                                             \
@@ -74,6 +82,7 @@ __device__ unsigned long long g_prof[24];
 #else
 #define NTE_PROF_DECL ((void)0)
 #define NTE_PROF_COUNT(slot) ((void)0)
+#define NTE_PROF_ADD(slot, n) ((void)0)
 #define NTE_PROF(slot) ((void)0)
 #define NTE_PROF_SUB(slot) ((void)0)
 #define NTE_PROF_FLUSH ((void)0)
@@ -93,7 +102,9 @@ struct EventEnv
 	u32 len;
 	u32 contig;
 	u64 gbase;      // global index of seq[0] in the batch (bitmap coordinates)
-	const u64* bitmap;
+	const u64* bitmap;  // 1 bit per k-mer start: all bases accepted and the k-mer absent (the screening pass)
+	const u64* runmap;  // the positions the serial walk stops at / goes on from: the same bitmap, or a subset of it that
+	                    // leaves out the positions whose assessment cannot do anything (k_assess, nte_assess.hip)
 	const u64* tab; // seed tables (LDS on the device)
 	const DevParams* p;
 	Filter bloom, rep;
@@ -147,10 +158,63 @@ struct Best
 	u32 altsupp1, altsupp2, altsupp3;
 };
 
-struct Machine
+// CFG: what the launch knows about its configuration at compile time.  The machine kernels are hundreds of KB of code
+// against a 64 KB instruction cache, and a wavefront walks through most of it once per event: every path a configuration
+// cannot take (counting filters, the secondary filter, -s 1, modes 1 / 2, -a, filters that are not a power of two) is
+// code it still drags through the cache.  CFG = 0 is the general machine.
+enum MachineCfg : u32
+{
+	CFG_MODE0 = 1, // -m 0 and no -a
+	CFG_PLAIN = 2, // plain Bloom filter(s), no -s 1
+	CFG_NOSEC = 4, // no secondary filter
+	CFG_POW2 = 8   // every filter's size is a power of two
+};
+
+template<u32 CFG>
+struct MachineT
 {
 	const EventEnv& e;
 	const DevParams& p;
+
+	NTE_HD u32 mode() const { return (CFG & CFG_MODE0) ? 0u : p.mode; }
+	NTE_HD bool mask() const { return (CFG & CFG_MODE0) ? false : p.mask != 0; }
+	NTE_HD bool snv() const { return (CFG & CFG_PLAIN) ? false : p.snv != 0; }
+	NTE_HD bool secbf() const { return (CFG & CFG_NOSEC) ? false : p.secbf != 0; }
+	NTE_HD bool counting() const { return (CFG & CFG_PLAIN) ? false : e.bloom.counting != 0; }
+	NTE_HD bool fcounting(const Filter& f) const { return (CFG & CFG_PLAIN) ? false : f.counting != 0; }
+	NTE_HD u64 slot(const Filter& f, u64 hv) const { return (CFG & CFG_POW2) ? (hv & f.mask) : filter_slot(f, hv); }
+
+	// btllib contains() / the counting filter's minimum (nte_common.h) with the configuration folded in
+	NTE_HD u32
+	min_count(const Filter& f, u64 base) const
+	{
+		u32 mn = 255;
+		for (unsigned i = 0; i < f.hash_num; i++) {
+			const u32 c = f.data[slot(f, hash_extend(base, p, i))];
+			mn = c < mn ? c : mn;
+			if (mn == 0) {
+				break;
+			}
+		}
+		return mn;
+	}
+
+	NTE_HD bool
+	contains(const Filter& f, const HashState& s) const
+	{
+		const u64 base = s.fh + s.rh;
+		if (fcounting(f)) {
+			return min_count(f, base) > 0;
+		}
+		for (unsigned i = 0; i < f.hash_num; i++) {
+			const u64 n = slot(f, hash_extend(base, p, i));
+			if (!((f.data[n >> 3] >> (n & 7)) & 1)) {
+				return false;
+			}
+		}
+		return true;
+	}
+
 	// cursors (ntedit.cpp:1773-1795)
 	u32 h_seq_i, t_seq_i, h_node, t_node;
 	HashState hs;
@@ -177,11 +241,11 @@ struct Machine
 	bool changed_seq; // the last failing position applied an edit (else the sequence, and the look-ahead, still stand)
 	bool la_win;      // the character window is still the one the look-ahead was hashed from (the stride needs it)
 #if defined(NTE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-	unsigned long long prof_sub_t = 0, prof_sub[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	unsigned long long prof_sub_t = 0, prof_sub[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, prof_cnt[4] = { 0, 0, 0, 0 };
 #endif
 
 	NTE_HD
-	Machine(const EventEnv& env)
+	MachineT(const EventEnv& env)
 	  : e(env)
 	  , p(*env.p)
 	{
@@ -514,14 +578,14 @@ struct Machine
 	in_bloom(const HashState& s) const
 	{
 		NTE_COUNT(probes, 1);
-		return filter_contains(e.bloom, p, s);
+		return contains(e.bloom, s);
 	}
 
 	// BFWrapper::get_count (ntedit.cpp:373-376): min counter, or 1 for a plain filter
 	NTE_HD u32
 	count_of(const HashState& s) const
 	{
-		return e.bloom.counting ? filter_min_count(e.bloom, p, s.fh + s.rh) : 1u;
+		return counting() ? min_count(e.bloom, s.fh + s.rh) : 1u;
 	}
 
 	// the main loop's test (ntedit.cpp:1806): not contained, or (counting) seen fewer than -p times
@@ -529,18 +593,22 @@ struct Machine
 	screen_absent(const HashState& s) const
 	{
 		NTE_COUNT(probes, 1);
-		return filter_screen_absent(e.bloom, p, s);
+		if (counting()) {
+			const u32 c = min_count(e.bloom, s.fh + s.rh);
+			return c == 0 || c < p.min_thr;
+		}
+		return !contains(e.bloom, s);
 	}
 
 	// is_kmer_solid (ntedit.cpp:465-473)
 	NTE_HD bool
 	solid(const HashState& s) const
 	{
-		if (p.secbf && filter_contains(e.rep, p, s)) {
+		if (secbf() && contains(e.rep, s)) {
 			return false;
 		}
-		if (e.bloom.counting) {
-			const u32 c = filter_min_count(e.bloom, p, s.fh + s.rh);
+		if (counting()) {
+			const u32 c = min_count(e.bloom, s.fh + s.rh);
 			return c <= p.max_thr && c >= p.min_thr;
 		}
 		return true;
@@ -572,7 +640,7 @@ struct Machine
 	{
 		u32 alive = ((1u << n) - 1) & only;
 		NTE_COUNT(probes, n);
-		if (f.counting) {
+		if (fcounting(f)) {
 			u8 mn[G];
 			NTE_UNROLL
 			for (int i = 0; i < G; i++) {
@@ -584,7 +652,7 @@ struct Machine
 				for (int i = 0; i < G; i++) {
 					byte[i] = 255;
 					if ((alive >> i) & 1) {
-						byte[i] = f.data[filter_slot(f, hash_extend(b[i], p, h))];
+						byte[i] = f.data[slot(f, hash_extend(b[i], p, h))];
 					}
 				}
 				NTE_UNROLL
@@ -612,7 +680,7 @@ struct Machine
 				byte[i] = 0xFF;
 				sh[i] = 0;
 				if ((alive >> i) & 1) {
-					const u64 sl = filter_slot(f, hash_extend(b[i], p, h));
+					const u64 sl = slot(f, hash_extend(b[i], p, h));
 					byte[i] = f.data[sl >> 3];
 					sh[i] = (u8)(sl & 7);
 				}
@@ -635,12 +703,12 @@ struct Machine
 		// contains() alone, or contains() && is_kmer_solid() (counter within [-p, -q] and not
 		// in the secondary filter)
 		u32 lo = 1, hi = 255;
-		if (solid_check && e.bloom.counting) {
+		if (solid_check && counting()) {
 			lo = p.min_thr > 1 ? p.min_thr : 1;
 			hi = p.max_thr;
 		}
 		u32 m = probe_group_range<G>(e.bloom, b, n, lo, hi);
-		if (solid_check && p.secbf && m) {
+		if (solid_check && secbf() && m) {
 			// the secondary filter only matters for k-mers that are present; members of it are not solid
 			const u32 in_rep = probe_group_range<G>(e.rep, b, n, 1, 255, m);
 			m &= ~in_rep;
@@ -1436,7 +1504,7 @@ struct Machine
 	try_indels(u8 draft_char, u8 index_char, u32& num_deletions, Best& b)
 	{
 		NTE_COUNT(sweeps, 1);
-		if (p.mode == 0 && win_ok) {
+		if (mode() == 0 && win_ok) {
 			return try_indels_first_accepted(draft_char, index_char, num_deletions, b) > 0;
 		}
 		u32 temp_best_support = 0, temp_alt_support = 0;
@@ -1478,7 +1546,7 @@ struct Machine
 			}
 			n_ins--; // drop the draft base again
 			if (check_present >= p.thr_edit) {
-				if (p.mode == 0) {
+				if (mode() == 0) {
 					b.edit_type = 2;
 					copy_bytes(b.indel, ins, n_ins);
 					b.n_indel = n_ins;
@@ -1501,7 +1569,7 @@ struct Machine
 				u32 n_deleted = 0;
 				u32 del_support = try_deletion(draft_char, num_deletions, deleted, n_deleted);
 				if (del_support > 0) {
-					if (p.mode == 0) {
+					if (mode() == 0) {
 						b.edit_type = 3;
 						copy_bytes(b.indel, deleted, n_deleted);
 						b.n_indel = n_deleted;
@@ -1523,7 +1591,7 @@ struct Machine
 		}
 
 		if (temp_best_support > 0) {
-			if ((p.mode == 2 && temp_best_support > b.num_support) || p.mode == 1) {
+			if ((mode() == 2 && temp_best_support > b.num_support) || mode() == 1) {
 				b.edit_type = temp_best_type;
 				copy_bytes(b.indel, temp_best_indel, temp_best_n);
 				b.n_indel = temp_best_n;
@@ -1631,7 +1699,7 @@ struct Machine
 			changelast(hs, draft_char, get_character(t_seq_i, nget(t_node)));
 			break;
 		case 0:
-			if (p.mask) {
+			if (mask()) {
 				u8 lc = (draft_char >= 'A' && draft_char <= 'Z') ? (u8)(draft_char + 32) : draft_char;
 				if (t_nd.type == 0) {
 					set_seq(t_seq_i, lc);
@@ -1642,7 +1710,7 @@ struct Machine
 				}
 				changelast(hs, draft_char, lc);
 			}
-			if (p.snv && b.altsupp1) {
+			if (snv() && b.altsupp1) {
 				// -s 1: a position that keeps its base but has supported alternatives is still
 				// reported (VCF only): sub_base == draft_char marks "no edit" (ntedit.cpp:1428-1443)
 				Item it;
@@ -1828,6 +1896,62 @@ struct Machine
 		la_win = true;
 	}
 
+	// ranks a substitution candidate that reached the support bar among the ones seen so far
+	// (best + up to three alternates, ntedit.cpp:1999-2050)
+	NTE_HD static void
+	note_candidate(Best& b, u8 sub_base, u32 check_present)
+	{
+		if (check_present >= b.num_support) {
+			if (b.altsupp2) {
+				b.altbase3 = b.altbase2;
+				b.altsupp3 = b.altsupp2;
+			}
+			if (b.altsupp1) {
+				b.altbase2 = b.altbase1;
+				b.altsupp2 = b.altsupp1;
+			}
+			if (b.num_support) {
+				b.altsupp1 = b.num_support;
+				b.altbase1 = b.sub_base;
+			}
+			b.edit_type = 1;
+			b.sub_base = sub_base;
+			b.num_support = check_present;
+		} else {
+			if (!b.altsupp1) {
+				b.altbase1 = sub_base;
+				b.altsupp1 = check_present;
+			} else if (!b.altsupp2) {
+				if (check_present < b.altsupp1) {
+					b.altbase2 = sub_base;
+					b.altsupp2 = check_present;
+				} else {
+					b.altbase2 = b.altbase1;
+					b.altsupp2 = b.altsupp1;
+					b.altbase1 = sub_base;
+					b.altsupp1 = check_present;
+				}
+			} else if (!b.altsupp3) {
+				if (check_present < b.altsupp2) {
+					b.altbase3 = sub_base;
+					b.altsupp3 = check_present;
+				} else if (check_present < b.altsupp1) {
+					b.altbase3 = b.altbase2;
+					b.altsupp3 = b.altsupp2;
+					b.altbase2 = sub_base;
+					b.altsupp2 = check_present;
+				} else {
+					b.altbase3 = b.altbase2;
+					b.altsupp3 = b.altsupp2;
+					b.altbase2 = b.altbase1;
+					b.altsupp2 = b.altsupp1;
+					b.altbase1 = sub_base;
+					b.altsupp1 = check_present;
+				}
+			}
+		}
+	}
+
 	// steps 2-5 + makeEdit for the k-mer currently under the cursors
 	NTE_HD void
 	process_missing(u8 char_in_at_t)
@@ -1847,7 +1971,7 @@ struct Machine
 		win_ok = fill_window();
 		NTE_PROF_SUB(0);
 		u32 check_there = 0, there_median = 0;
-		if (e.bloom.counting || p.snv) {
+		if (counting() || snv()) {
 			// counting filter / SNV mode (ntedit.cpp:1842-1861,1873,1890-1914): besides the
 			// missing count, the k-mers that ARE there matter -- their median coverage decides
 			// whether a fix is attempted, and in SNV mode their number is the draft base's own
@@ -1870,7 +1994,7 @@ struct Machine
 					break;
 				}
 				if (k % p.jump == 0) {
-					const u32 c = e.bloom.counting ? count_of(ts) : (in_bloom(ts) ? 1u : 0u);
+					const u32 c = counting() ? count_of(ts) : (in_bloom(ts) ? 1u : 0u);
 					if (c == 0) {
 						check_missing++;
 					} else if ((draft_char == 'A' || draft_char == 'C' || draft_char == 'G' || draft_char == 'T') &&
@@ -1898,8 +2022,8 @@ struct Machine
 				median = e.prev[nm / 2];
 			}
 			there_median = median;
-			if (!p.snv &&
-			    (do_not_fix || !(check_missing >= p.thr_missing || (e.bloom.counting && median < p.min_thr)))) {
+			if (!snv() &&
+			    (do_not_fix || !(check_missing >= p.thr_missing || (counting() && median < p.min_thr)))) {
 				return;
 			}
 		} else if (win_ok && wc_valid && is_clean()) {
@@ -1947,7 +2071,7 @@ struct Machine
 				break;
 			}
 		}
-		if ((!p.snv && (do_not_fix || (!e.bloom.counting && check_missing < p.thr_missing))) || p.debug_stop == 2) {
+		if ((!snv() && (do_not_fix || (!counting() && check_missing < p.thr_missing))) || p.debug_stop == 2) {
 			return;
 		}
 
@@ -1960,20 +2084,20 @@ struct Machine
 		b.num_support = 0;
 		b.altbase1 = b.altbase2 = b.altbase3 = 0;
 		b.altsupp1 = b.altsupp2 = b.altsupp3 = 0;
-		if (p.snv && check_there >= p.thr_edit) {
+		if (snv() && check_there >= p.thr_edit) {
 			// the draft base's own support is the bar (ntedit.cpp:1890-1903)
 			b.sub_base = draft_char;
-			b.num_support = e.bloom.counting ? there_median : check_there;
+			b.num_support = counting() ? there_median : check_there;
 		}
 
 		u8 cand[4];
-		u32 n_cand = candidate_bases(draft_char, p.snv != 0, cand);
+		u32 n_cand = candidate_bases(draft_char, snv(), cand);
 		Node t_nd = nget(t_node);
 		for (u32 ci = 0; ci < n_cand; ci++) {
 			u8 sub_base = cand[ci];
 			ts = hs;
 			changelast(ts, draft_char, sub_base);
-			if (!(present_solid(ts) || p.mode == 2)) {
+			if (!(present_solid(ts) || mode() == 2)) {
 				continue;
 			}
 			th = h_seq_i;
@@ -2026,60 +2150,12 @@ struct Machine
 			}
 
 			if (check_present >= p.thr_edit) {
-				if (check_present >= b.num_support) {
-					if (b.altsupp2) {
-						b.altbase3 = b.altbase2;
-						b.altsupp3 = b.altsupp2;
-					}
-					if (b.altsupp1) {
-						b.altbase2 = b.altbase1;
-						b.altsupp2 = b.altsupp1;
-					}
-					if (b.num_support) {
-						b.altsupp1 = b.num_support;
-						b.altbase1 = b.sub_base;
-					}
-					b.edit_type = 1;
-					b.sub_base = sub_base;
-					b.num_support = check_present;
-				} else {
-					if (!b.altsupp1) {
-						b.altbase1 = sub_base;
-						b.altsupp1 = check_present;
-					} else if (!b.altsupp2) {
-						if (check_present < b.altsupp1) {
-							b.altbase2 = sub_base;
-							b.altsupp2 = check_present;
-						} else {
-							b.altbase2 = b.altbase1;
-							b.altsupp2 = b.altsupp1;
-							b.altbase1 = sub_base;
-							b.altsupp1 = check_present;
-						}
-					} else if (!b.altsupp3) {
-						if (check_present < b.altsupp2) {
-							b.altbase3 = sub_base;
-							b.altsupp3 = check_present;
-						} else if (check_present < b.altsupp1) {
-							b.altbase3 = b.altbase2;
-							b.altsupp3 = b.altsupp2;
-							b.altbase2 = sub_base;
-							b.altsupp2 = check_present;
-						} else {
-							b.altbase3 = b.altbase2;
-							b.altsupp3 = b.altsupp2;
-							b.altbase2 = b.altbase1;
-							b.altsupp2 = b.altsupp1;
-							b.altbase1 = sub_base;
-							b.altsupp1 = check_present;
-						}
-					}
-				}
-				if (p.mode == 0 || p.mode == 1) {
+				note_candidate(b, sub_base, check_present);
+				if (mode() == 0 || mode() == 1) {
 					continue;
 				}
 			}
-			if (p.mode == 2 || b.edit_type != 1) {
+			if (mode() == 2 || b.edit_type != 1) {
 				if (p.debug_stop == 3) {
 					return; // timing ablation: everything up to the first indel sweep
 				}
@@ -2093,7 +2169,7 @@ struct Machine
 					// candidates are tried here, in list order -- the first accepted one is the sweep's
 					// result whatever comes behind it.
 					int r = -1;
-					if (p.mode == 0 && win_ok && p.inline_tries) {
+					if (mode() == 0 && win_ok && p.inline_tries) {
 						r = try_indels_first_accepted(draft_char, sub_base, num_deletions, b, p.inline_tries);
 					}
 					if (r < 0) {
@@ -2107,7 +2183,7 @@ struct Machine
 					NTE_PROF_SUB(4); // indel sweep
 				}
 				if (accepted) {
-					if (p.mode == 0 || p.mode == 1) {
+					if (mode() == 0 || mode() == 1) {
 						break;
 					}
 				}
@@ -2119,7 +2195,674 @@ struct Machine
 		NTE_PROF_SUB(3);
 	}
 
+
+	// ------------------------------------------------------------ runs of failing positions, one position per lane
+	// A failing position that ends without an edit leaves the machine exactly where it was: the assessment of the next
+	// position is a function of the (edited) sequence and the filter alone.  While both cursors sit in the open last
+	// position node ("linear": the edited sequence from the head on is the draft with the overlay applied) the next
+	// 64 positions are therefore assessed TOGETHER, lane i taking position q + i: every lane runs the same phases on its
+	// own offset of one shared character window -- presence of its k-mer where the window still holds a substituted base,
+	// step 2, the substitution candidates (ntedit.cpp:1826-2062) -- which tells it whether its position ends with no edit,
+	// with a substitution, or needs an indel sweep.  Then the positions are taken in serial order: the first one that
+	// is not a plain "no edit" gets its sweeps (all lanes on the candidates of that one position, as before) and, if an
+	// edit comes out, the machine is placed there and applies it; everything the lanes behind it computed is dropped
+	// (the serial program would have assessed them in another state).  First edit wins + restart is the reference's
+	// order, position by position (ntedit.cpp:1798-2139).  On the host (tests/hostsim) the lanes are a loop.
+	static constexpr u32 N_LANES = 64;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+	template<typename T>
+	struct PerLane
+	{
+		T v;
+		NTE_HD T& at(u32) { return v; }
+	};
+#define NTE_FOR_LANES(l, n) for (u32 l = wave_lane(), nte_once_ = 1; nte_once_ && l < (n); nte_once_ = 0)
+#else
+	template<typename T>
+	struct PerLane
+	{
+		T v[N_LANES];
+		NTE_HD T& at(u32 l) { return v[l]; }
+	};
+#define NTE_FOR_LANES(l, n) for (u32 l = 0; l < (n); l++)
+#endif
+
+	// value of lane `src`
+	NTE_HD u32
+	lanes_get(PerLane<u32>& x, u32 src) const
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		return (u32)__shfl((int)x.v, (int)src, 64);
+#else
+		return x.v[src];
+#endif
+	}
+
+	NTE_HD u64
+	lanes_get(PerLane<u64>& x, u32 src) const
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		const u32 lo = (u32)__shfl((int)(u32)x.v, (int)src, 64);
+		const u32 hi = (u32)__shfl((int)(u32)(x.v >> 32), (int)src, 64);
+		return ((u64)hi << 32) | lo;
+#else
+		return x.v[src];
+#endif
+	}
+
+	// lowest lane in [from, n) whose value is not zero; n if there is none
+	NTE_HD u32
+	lanes_first(PerLane<u32>& x, u32 from, u32 n) const
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		const u32 l = wave_lane();
+		const u64 m = __ballot(l >= from && l < n && x.v != 0);
+		return m ? (u32)__builtin_ctzll(m) : n;
+#else
+		for (u32 l = from; l < n; l++) {
+			if (x.v[l]) {
+				return l;
+			}
+		}
+		return n;
+#endif
+	}
+
+	// stores of one lane become visible to the others of its wavefront
+	NTE_HD void
+	lanes_sync() const
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+	}
+
+	// both cursors in the open last position node, k draft positions apart: is_clean() without the test for
+	// substituted bases inside the window
+	NTE_HD bool
+	linear() const
+	{
+		if (h_node != t_node) {
+			return false;
+		}
+		Node n = nget(t_node);
+		if (n.type != 0 || n.e_pos != e.len - 1) {
+			return false;
+		}
+		if (t_node + 1 < nsize && nget(t_node + 1).type != -1) {
+			return false;
+		}
+		return t_seq_i == h_seq_i + p.k - 1 && h_seq_i >= n.s_pos;
+	}
+
+	NTE_HD static u8
+	code_letter(u8 code)
+	{
+		// the accepted bases by code (char_code): upper case
+		return code < 14 ? (u8)"ACGTRYSWKMBDHV"[code] : (u8)'N';
+	}
+
+	// i-th of up to 16 counts packed into two words
+	NTE_HD static u32
+	packed_byte(u64 lo, u64 hi, u32 i)
+	{
+		return (u32)(((i < 8 ? lo : hi) >> (8 * (i & 7))) & 0xFF);
+	}
+
+	// what one lane knows about its position after the phases every lane runs by itself
+	enum LaneState : u32
+	{
+		LANE_NONE = 0,   // the position ends without an edit
+		LANE_EDIT = 1,   // a substitution (no indel sweep on the way to it)
+		LANE_SWEEP = 2   // the outcome depends on an indel sweep
+	};
+
+	// The candidate loop of a failing position (ntedit.cpp:1916-2062) replayed from the candidates' substitution
+	// support: S[ci] = bit 31 "the k-mer with candidate ci in place of the draft base is there", low bits = its
+	// support on the k/j subset.  sweeps = false: stop where an indel sweep would start (LANE_SWEEP);
+	// sweeps = true: run them (all lanes of the wavefront on that one position; hs / win_off are that position's).
+	NTE_HD u32
+	decide_position(const u32 (&S)[4], u8 draft_char, u32 check_there, u32 there_median, bool sweeps, Best& b)
+	{
+		b.edit_type = 0;
+		b.n_indel = 0;
+		b.sub_base = 0;
+		b.num_support = 0;
+		b.altbase1 = b.altbase2 = b.altbase3 = 0;
+		b.altsupp1 = b.altsupp2 = b.altsupp3 = 0;
+		if (snv() && check_there >= p.thr_edit) {
+			b.sub_base = draft_char;
+			b.num_support = counting() ? there_median : check_there;
+		}
+		u8 cand[4];
+		const u32 n_cand = candidate_bases(draft_char, snv(), cand);
+		u32 num_deletions = 1;
+		for (u32 ci = 0; ci < n_cand; ci++) {
+			if (!(S[ci] >> 31)) {
+				continue;
+			}
+			const u32 sup = S[ci] & 0x7FFFFFFFu;
+			if (sup >= p.thr_edit) {
+				note_candidate(b, cand[ci], sup);
+				continue;
+			}
+			if (b.edit_type != 1 && p.ins_tries > 0) {
+				if (!sweeps) {
+					return LANE_SWEEP;
+				}
+				if (try_indels_first_accepted(draft_char, cand[ci], num_deletions, b) > 0) {
+					break;
+				}
+			}
+		}
+		return b.edit_type ? LANE_EDIT : LANE_NONE;
+	}
+
+	// how many of the positions q, q + 1, ... the serial program walks through if none of them makes an edit (<= 64):
+	// a position whose window still holds a substituted base is walked whatever the filter says; elsewhere the walk goes
+	// on while the screening bitmap has the k-mer absent and no other event starts there.  Every one of them needs the
+	// full character window inside the contig.
+	NTE_HD u32
+	lanes_run_length(u32 q) const
+	{
+		const u32 K = win_len_in();
+#if defined(__HIP_DEVICE_COMPILE__)
+		const u32 l = wave_lane();
+		const u64 P = (u64)q + l;
+		bool ok = P + p.k - 1 + K <= (u64)e.len - 1;
+		if (ok && l > 0 && (int64_t)P > last_sub_pos) {
+			const u64 g = e.gbase + P;
+			ok = bit_absent(e.runmap, g) && !is_event_start(e.runmap, g, p.start_grid);
+		}
+		const u64 m = ~__ballot(ok);
+		return m ? (u32)__builtin_ctzll(m) : N_LANES;
+#else
+		u32 n = 0;
+		for (u32 l = 0; l < N_LANES; l++) {
+			const u64 P = (u64)q + l;
+			bool ok = P + p.k - 1 + K <= (u64)e.len - 1;
+			if (ok && l > 0 && (int64_t)P > last_sub_pos) {
+				const u64 g = e.gbase + P;
+				ok = bit_absent(e.runmap, g) && !is_event_start(e.runmap, g, p.start_grid);
+			}
+			if (!ok) {
+				break;
+			}
+			n++;
+		}
+		return n;
+#endif
+	}
+
+	// character codes of the edited sequence from position q on for n lanes, into the shared window.  false: a byte
+	// the 4-bit codes cannot express (see fill_window) -- the caller takes the reference-shaped paths.  *n_io shrinks
+	// to the lanes whose k-mer holds accepted bases only.
+	NTE_HD bool
+	lanes_fill_window(u32 q, u32* n_io)
+	{
+		const u32 K = win_len_in();
+		u32 n = *n_io;
+		u32 want = (n - 1) + p.k + K + WIN_AHEAD;
+		const u64 room = (u64)e.len - q;
+		if (want > room) {
+			want = (u32)room;
+		}
+		const u8* src = e.seq + q;
+		const u32 W = e.wave_size;
+		bool exotic = false;
+		u32 first_bad = 0xFFFFFFFFu; // (per lane: the lowest index it saw)
+		for (u32 i = wave_lane(); i < want; i += W) {
+			const u8 ch = src[i];
+			const u8 code = char_code(ch);
+			exotic |= code == CODE_BAD && is_exotic(ch);
+			if (code == CODE_BAD && first_bad == 0xFFFFFFFFu) {
+				first_bad = i;
+			}
+			e.win[(u64)i * e.win_stride] = code;
+		}
+		if (wave_ballot(exotic)) {
+			wc_valid = false;
+			return false;
+		}
+		lanes_sync();
+		// modified draft characters (substituted bases, changes of case)
+		for (u32 i = 0; i < n_ov; i++) {
+			const u32 op = e.ov_pos[i];
+			if (op >= q && op - q < want) {
+				e.win[(u64)(op - q) * e.win_stride] = char_code(e.ov_chr[i]);
+			}
+		}
+		lanes_sync();
+		// the first non-accepted character ends the stretch (the main loop skips over it, ntedit.cpp:2119-2138)
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (W > 1) {
+			for (u32 off = 32; off > 0; off >>= 1) {
+				const u32 o = (u32)__shfl_xor((int)first_bad, (int)off, 64);
+				first_bad = o < first_bad ? o : first_bad;
+			}
+		}
+#endif
+		if (first_bad != 0xFFFFFFFFu) {
+			// lane l reads window bytes l .. l + k - 1 for its own k-mer
+			const u32 lim = first_bad >= p.k ? first_bad - p.k + 1 : 0;
+			if (lim < n) {
+				n = lim;
+			}
+		}
+		wc_valid = n_ov == 0;
+		wc_pos0 = q;
+		wc_len = want;
+		*n_io = n;
+		return n > 0;
+	}
+
+	// presence (members of the filter; solid_check as present_group) of up to 16 subset k-mers of a walk at once is not
+	// needed here: the walks below go through subset_scan, which probes 8 at a time.
+
+	// step 2 for one lane when the counts matter (counting filter / SNV mode, ntedit.cpp:1842-1861,1873,1890-1914):
+	// missing subset k-mers, the subset k-mers that are there (check_there) and the median of their counts.
+	// false = do_not_fix (a non-accepted character enters)
+	NTE_HD bool
+	lane_step2_counts(u8 draft_char, u32& check_missing, u32& check_there, u32& there_median) const
+	{
+		HashState ts = hs;
+		u64 c_lo = 0, c_hi = 0;
+		check_missing = 0;
+		check_there = 0;
+		there_median = 0;
+		const bool acgt = draft_char == 'A' || draft_char == 'C' || draft_char == 'G' || draft_char == 'T';
+		const u32 lo = 1, hi = 255;
+		(void)lo;
+		(void)hi;
+		u32 k = 0;
+		bool ok = true;
+		while (k < p.k && ok) {
+			u64 b[8];
+			u32 nb = 0;
+			NTE_UNROLL
+			for (int u = 0; u < 8; u++) {
+				b[u] = 0;
+				if (nb == (u32)u) {
+					while (k < p.k) {
+						const u8 in = win_i(k);
+						hash_roll(ts, e.tab, win_o(k), in);
+						if (in == CODE_BAD) {
+							ok = false;
+							break;
+						}
+						const bool is_sub = (k % p.jump) == 0;
+						k++;
+						if (is_sub) {
+							b[u] = ts.fh + ts.rh;
+							nb = (u32)u + 1;
+							break;
+						}
+					}
+				}
+			}
+			if (nb == 0) {
+				break;
+			}
+			// (the k-mers gathered before a non-accepted character are counted as the serial loop counts them)
+			u8 mn[8];
+			count_group<8>(e.bloom, b, nb, mn);
+			NTE_UNROLL
+			for (int u = 0; u < 8; u++) {
+				if ((u32)u < nb) {
+					const u32 c = mn[u];
+					if (c == 0) {
+						check_missing++;
+					} else if (acgt && c >= p.min_thr) {
+						if (check_there < 16) {
+							if (check_there < 8) {
+								c_lo |= (u64)c << (8 * check_there);
+							} else {
+								c_hi |= (u64)c << (8 * (check_there - 8));
+							}
+						}
+						check_there++;
+					}
+				}
+			}
+		}
+		// median (ntedit.cpp:455-463): element n/2 of the sorted counts
+		const u32 nm = check_there;
+		if (nm) {
+			for (u32 i = 0; i < nm; i++) {
+				const u32 vi = packed_byte(c_lo, c_hi, i);
+				u32 rank = 0;
+				for (u32 j = 0; j < nm; j++) {
+					const u32 vj = packed_byte(c_lo, c_hi, j);
+					rank += (vj < vi || (vj == vi && j < i)) ? 1u : 0u;
+				}
+				if (rank == nm / 2) {
+					there_median = vi;
+					break;
+				}
+			}
+		}
+		return ok;
+	}
+
+	// smallest counter of up to G k-mers (plain filter: 1 = contained, 0 = not), level by level
+	template<int G>
+	NTE_HD void
+	count_group(const Filter& f, const u64 (&b)[G], u32 n, u8 (&mn)[G]) const
+	{
+		NTE_COUNT(probes, n);
+		if (!fcounting(f)) {
+			const u32 m = probe_group_range<G>(f, b, n, 1, 255);
+			NTE_UNROLL
+			for (int i = 0; i < G; i++) {
+				mn[i] = (u8)((m >> i) & 1);
+			}
+			return;
+		}
+		u32 alive = (1u << n) - 1;
+		NTE_UNROLL
+		for (int i = 0; i < G; i++) {
+			mn[i] = 255;
+		}
+		for (u32 h = 0; h < f.hash_num && alive; h++) {
+			u8 byte[G];
+			NTE_UNROLL
+			for (int i = 0; i < G; i++) {
+				byte[i] = 255;
+				if ((alive >> i) & 1) {
+					byte[i] = f.data[slot(f, hash_extend(b[i], p, h))];
+				}
+			}
+			NTE_UNROLL
+			for (int i = 0; i < G; i++) {
+				mn[i] = byte[i] < mn[i] ? byte[i] : mn[i];
+				if (mn[i] == 0) {
+					alive &= ~(1u << i);
+				}
+			}
+		}
+	}
+
+	// The phases one lane runs by itself for the position whose k-mer starts at window offset win_off with hash hs.
+	// dirty: the window holds a substituted base (the screening bitmap does not speak for these k-mers).
+	// GATE (k_assess): the same answer, cheapest test first -- without a candidate whose own k-mer is there the position
+	// cannot do anything (no substitution, no indel sweep -- its index base is such a candidate --, no upper-cased
+	// revert, no -s 1 report), whatever step 2 says; one position in a hundred gets past that test
+	template<bool GATE = false>
+	NTE_HD u32
+	assess_lane(u64 g_pos, bool dirty, u32 (&S)[4], u8& draft_char_out, u32& check_there, u32& there_median, bool& reverted)
+	{
+		S[0] = S[1] = S[2] = S[3] = 0;
+		check_there = 0;
+		there_median = 0;
+		reverted = false;
+		const u8 draft_code = win_o(p.k - 1);
+		const u8 draft_char = code_letter(draft_code);
+		draft_char_out = draft_char;
+		// the main loop's test of the k-mer under the cursors (ntedit.cpp:1806)
+		if (dirty && !snv() && !screen_absent(hs)) {
+			return LANE_NONE;
+		}
+		// the substitution candidates (ntedit.cpp:1916-1934); their changed k-mers are probed together
+		u8 cand[4];
+		const u32 n_cand = candidate_bases(draft_char, snv(), cand);
+		u64 cb[4];
+		HashState cts[4];
+		NTE_UNROLL
+		for (int ci = 0; ci < 4; ci++) {
+			cts[ci] = hs;
+			cb[ci] = 0;
+			if ((u32)ci < n_cand) {
+				hash_changelast(cts[ci], e.tab, draft_code, char_code(cand[ci]));
+				cb[ci] = cts[ci].fh + cts[ci].rh;
+			}
+		}
+		u32 there = 0;
+		const bool gate_first = GATE && mode() != 2 && !mask();
+		if (gate_first) {
+			there = n_cand ? present_group<4>(cb, n_cand, true) : 0;
+			if (!there) {
+				return LANE_NONE;
+			}
+		}
+		// step 2 (ntedit.cpp:1826-1873)
+		u32 check_missing = 0;
+		if (counting() || snv()) {
+			const bool ok = lane_step2_counts(draft_char, check_missing, check_there, there_median);
+			if (!snv() && (!ok || !(check_missing >= p.thr_missing || (counting() && there_median < p.min_thr)))) {
+				return LANE_NONE;
+			}
+		} else if (!dirty) {
+			for (u32 k = 0; k < p.k; k++) {
+				if (win_i(k) == CODE_BAD) {
+					return LANE_NONE;
+				}
+			}
+			const u64 g = g_pos + 1;
+			for (u32 k = 0; k < p.k; k += p.jump) {
+				check_missing += bit_absent(e.bitmap, g + k) ? 1u : 0u;
+			}
+			if (check_missing < p.thr_missing) {
+				return LANE_NONE;
+			}
+		} else {
+			const SubsetResult r =
+			    subset_scan<8>(hs, 0, p.k - 1, false, false, 0, 0, p.thr_missing, [&](u32 k, HashState& t) {
+				    const u8 in = win_i(k);
+				    hash_roll(t, e.tab, win_o(k), in);
+				    return in != CODE_BAD;
+			    });
+			if (r.aborted || r.gave_up || r.total - r.present < p.thr_missing) {
+				return LANE_NONE;
+			}
+		}
+		if (GATE && !gate_first) {
+			return LANE_EDIT; // -m 2 sweeps every candidate whether its k-mer is there or not; -a masks the base
+		}
+		// step 3: the candidates' support
+		if (!gate_first) {
+			there = n_cand ? present_group<4>(cb, n_cand, true) : 0;
+		}
+		NTE_UNROLL
+		for (int ci = 0; ci < 4; ci++) {
+			if ((u32)ci < n_cand && ((there >> ci) & 1)) {
+				reverted = true;
+				const u8 sub_code = char_code(cand[ci]);
+				const u32 last = p.k - 1;
+				const SubsetResult r =
+				    subset_scan<8>(cts[ci], 0, last, true, false, 0, p.thr_edit, 0, [&](u32 k, HashState& t) {
+					    hash_roll(t, e.tab, k == last ? sub_code : win_o(k), win_i(k));
+					    return true;
+				    });
+				S[ci] = 0x80000000u | (r.gave_up ? 0u : r.present);
+			}
+		}
+		Best b;
+		return decide_position(S, draft_char, check_there, there_median, false, b);
+	}
+
+	// what a position leaves behind even without an edit: bit 0 the upper-cased draft base of the substitution revert
+	// (ntedit.cpp:1975-1981; where the draft byte differs), bit 1 -- -s 1 -- a position that keeps its base but may have
+	// supported alternatives to report (only a candidate that reached the support bar can become one)
+	NTE_HD u32
+	lane_leftovers(u32 state, const u32 (&S)[4], bool reverted, u8 draft_byte, u8 draft_char) const
+	{
+		u32 out = (reverted && draft_byte != draft_char) ? 1u : 0u;
+		if (snv() && state == LANE_NONE) {
+			for (int ci = 0; ci < 4; ci++) {
+				if ((S[ci] >> 31) && (S[ci] & 0x7FFFFFFFu) >= p.thr_edit) {
+					out |= 2u;
+				}
+			}
+		}
+		return out;
+	}
+
+	// k_assess / its host twin: can the clean-state assessment of the position whose k-mer starts at window offset
+	// win_off (hash in hs) do anything at all?  The window holds k + win_len_in() accepted codes from there on;
+	// draft_byte = the draft's own byte under the last base of the k-mer.
+	NTE_HD bool
+	assess_gate(u64 g_pos, u8 draft_byte)
+	{
+		u32 S[4];
+		u8 dc = 0;
+		u32 ct = 0, med = 0;
+		bool rev = false;
+		const u32 st = assess_lane<true>(g_pos, false, S, dc, ct, med, rev);
+		return st != LANE_NONE || lane_leftovers(st, S, rev, draft_byte, dc) != 0;
+	}
+
+	// hash of the k-mer at window offset win_off (seed of ntedit.cpp:412-413 on the window codes)
+	NTE_HD HashState
+	seed_from_window() const
+	{
+		HashState s;
+		s.fh = 0;
+		s.rh = 0;
+		for (u32 i = 0; i < p.k; i++) {
+			s.fh = srol1(s.fh) ^ e.tab[TAB_F + win_o(i)];
+		}
+		for (u32 i = p.k; i > 0; i--) {
+			s.rh = srol1(s.rh) ^ e.tab[TAB_R + win_o(i - 1)];
+		}
+		return s;
+	}
+
+	// One batch of positions from the cursors on.  false: nothing was done (the window cannot be used here), the
+	// caller assesses this position the serial way.  true: the machine stands at the last position the batch dealt
+	// with -- the one whose edit it applied (changed_seq), or the last of a stretch without any -- ready to roll on;
+	// walked = positions it went through.
+	NTE_HD bool
+	run_lanes(u32& walked)
+	{
+		const u32 q = h_seq_i;
+		NTE_PROF_SUB(7); // (time outside)
+		u32 n = lanes_run_length(q);
+		if (n == 0 || !lanes_fill_window(q, &n)) {
+			return false;
+		}
+		NTE_PROF_SUB(0); // run length + window
+		NTE_PROF_ADD(2, 1);
+		NTE_PROF_ADD(3, n);
+		win_ok = true;
+		NTE_COUNT(lane_batches, 1);
+		NTE_COUNT(lane_positions, n);
+		PerLane<u64> l_fh, l_rh;
+		PerLane<u32> l_state, l_s0, l_s1, l_s2, l_s3, l_there, l_median, l_out;
+		const HashState keep_hs = hs;
+		NTE_FOR_LANES(l, N_LANES)
+		{
+			l_state.at(l) = LANE_NONE;
+			l_out.at(l) = 0;
+			l_fh.at(l) = l_rh.at(l) = 0;
+			l_s0.at(l) = l_s1.at(l) = l_s2.at(l) = l_s3.at(l) = 0;
+			l_there.at(l) = l_median.at(l) = 0;
+		}
+		NTE_FOR_LANES(l, n)
+		{
+			win_off = l;
+			const HashState s = seed_from_window();
+			hs = s;
+			u32 S[4];
+			u8 dc = 0;
+			u32 ct = 0, med = 0;
+			bool rev = false;
+			const u64 P = (u64)q + l;
+			const u32 st = assess_lane(e.gbase + P, (int64_t)P <= last_sub_pos, S, dc, ct, med, rev);
+			l_fh.at(l) = s.fh;
+			l_rh.at(l) = s.rh;
+			l_state.at(l) = st;
+			l_s0.at(l) = S[0];
+			l_s1.at(l) = S[1];
+			l_s2.at(l) = S[2];
+			l_s3.at(l) = S[3];
+			l_there.at(l) = ct;
+			l_median.at(l) = med;
+			l_out.at(l) = lane_leftovers(st, S, rev, e.seq[P + p.k - 1], dc) | ((u32)dc << 8);
+		}
+		hs = keep_hs;
+		NTE_PROF_SUB(2); // the lanes' own phases
+		// ---- serial order: the first position that is not a plain "no edit"
+		u32 f = n; // lane of the edit (n = none)
+		Best b;
+		b.edit_type = 0;
+		u32 from = 0;
+		while (from < n) {
+			const u32 c = lanes_first(l_state, from, n);
+			if (c >= n) {
+				break;
+			}
+			u32 S[4];
+			S[0] = lanes_get(l_s0, c);
+			S[1] = lanes_get(l_s1, c);
+			S[2] = lanes_get(l_s2, c);
+			S[3] = lanes_get(l_s3, c);
+			const u8 dc = (u8)(lanes_get(l_out, c) >> 8);
+			hs.fh = lanes_get(l_fh, c);
+			hs.rh = lanes_get(l_rh, c);
+			win_off = c;
+			const u32 st = decide_position(S, dc, lanes_get(l_there, c), lanes_get(l_median, c), true, b);
+			if (st == LANE_EDIT) {
+				f = c;
+				break;
+			}
+			from = c + 1; // its sweeps found nothing
+		}
+		NTE_PROF_SUB(4); // replay + indel sweeps
+		// ---- what the positions in front of the edit (and the edit's own revert) leave behind, in order
+		const u32 upto = f < n ? f + 1 : n;
+		u32 from_out = 0;
+		while (from_out < upto) {
+			PerLane<u32> flag;
+			NTE_FOR_LANES(l, N_LANES) { flag.at(l) = l_out.at(l) & 3u; }
+			const u32 c = lanes_first(flag, from_out, upto);
+			if (c >= upto) {
+				break;
+			}
+			const u32 o = lanes_get(l_out, c);
+			const u8 dc = (u8)(o >> 8);
+			if (o & 1u) {
+				set_seq(q + c + p.k - 1, dc);
+			}
+			if ((o & 2u) && c != f) {
+				u32 S[4];
+				S[0] = lanes_get(l_s0, c);
+				S[1] = lanes_get(l_s1, c);
+				S[2] = lanes_get(l_s2, c);
+				S[3] = lanes_get(l_s3, c);
+				Best nb;
+				decide_position(S, dc, lanes_get(l_there, c), lanes_get(l_median, c), false, nb);
+				if (nb.edit_type == 0 && nb.altsupp1) {
+					t_seq_i = q + c + p.k - 1; // (make_edit reports the tail position)
+					make_edit(dc, nb);
+				}
+			}
+			from_out = c + 1;
+		}
+		// ---- place the machine
+		const u32 at = f < n ? f : n - 1;
+		h_seq_i = q + at;
+		t_seq_i = q + at + p.k - 1;
+		hs.fh = lanes_get(l_fh, at);
+		hs.rh = lanes_get(l_rh, at);
+		win_off = at;
+		walked = at + 1;
+		NTE_COUNT(lane_walked, walked);
+		changed_seq = false;
+		if (f < n) {
+			NTE_COUNT(lane_edits, 1);
+			changed_seq = true;
+			make_edit((u8)(lanes_get(l_out, f) >> 8), b);
+		}
+		NTE_PROF_SUB(3); // what the positions leave behind, placing the machine, applying
+		return true;
+	}
+
 	// run one event that starts (clean) with its k-mer head at local position start
+	// LANES: runs of failing positions go through run_lanes() (the wavefront-per-event kernel; the host build)
+	template<bool LANES = false>
 	NTE_HD void
 	run(u32 start, u32& cover_end)
 	{
@@ -2218,15 +2961,38 @@ struct Machine
 				break;
 			}
 			bool missing;
-			if (is_clean()) {
+			const bool clean = is_clean();
+			if (clean) {
 				u64 g = e.gbase + h_seq_i;
-				if (!first && (!bit_absent(e.bitmap, g) || is_event_start(e.bitmap, g, p.start_grid))) {
+				if (!first && (!bit_absent(e.runmap, g) || is_event_start(e.runmap, g, p.start_grid))) {
 					cover_end = h_seq_i;
 					break;
 				}
+			}
+			bool in_lanes = false;
+			if (LANES && p.lanes && mode() == 0 && !mask() && !p.debug_stop && e.win && (clean || (p.lanes > 1 && linear()))) {
+				// this position and the ones behind it, one per lane
+				u32 walked = 0;
+				in_lanes = run_lanes(walked);
+				if (in_lanes) {
+					steps += walked - 1;
+					la_n = la_i = 0;
+					la_off = false;
+					la_win = false;
+				}
+			}
+			const bool was_first = first;
+			first = false;
+			if (in_lanes) {
+				missing = true;
+				NTE_PROF(was_first ? 2 : 3);
+				NTE_PROF_COUNT(0);
+				NTE_PROF_COUNT(1);
+			} else {
+			if (clean) {
 				missing = true; // clean state: the screening bitmap already answered
 			} else {
-				if (p.snv) {
+				if (snv()) {
 					missing = true;
 				} else {
 					if (la_i >= la_n && !la_off) {
@@ -2239,10 +3005,8 @@ struct Machine
 					}
 				}
 			}
-			const bool was_first = first;
 			NTE_PROF(1); // presence of the k-mer at the cursor (look-ahead included)
 			NTE_PROF_COUNT(0);
-			first = false;
 			if (missing) {
 				NTE_PROF_COUNT(1);
 				changed_seq = false;
@@ -2254,6 +3018,20 @@ struct Machine
 					la_off = false;
 				}
 				// (an error nothing fixes fails at every k-mer that covers it: the k-mers ahead are the same ones)
+				if (!LANES && e.defer_sweeps && p.defer_run && !changed_seq && clean && mode() == 0 && !mask() && p.lanes &&
+				    !(flags & EV_DEFERRED)) {
+					// A clean position that ends without an edit: if the absent run goes on, the following positions
+					// are assessed one per lane by the wavefront-per-event launch instead of one after the other here.
+					u32 more = 0;
+					const u64 g1 = e.gbase + h_seq_i + 1;
+					while (more < p.defer_run && bit_absent(e.runmap, g1 + more) && !is_event_start(e.runmap, g1 + more, p.start_grid)) {
+						more++;
+					}
+					if (more >= p.defer_run) {
+						flags |= EV_DEFERRED;
+					}
+				}
+			}
 			}
 			if (p.debug_stop >= 2 && p.debug_stop < 8) {
 				cover_end = e.len;
@@ -2389,5 +3167,27 @@ struct Machine
 		return first_chunk;
 	}
 };
+
+typedef MachineT<0> Machine; // the general machine
+
+// the most specific machine a configuration allows (host side: which kernel / host instantiation to use)
+inline u32
+machine_cfg_of(const DevParams& p, const Filter& bloom, const Filter& rep)
+{
+	u32 cfg = 0;
+	if (p.mode == 0 && !p.mask) {
+		cfg |= CFG_MODE0;
+	}
+	if (!bloom.counting && !(p.secbf && rep.counting) && !p.snv) {
+		cfg |= CFG_PLAIN;
+	}
+	if (!p.secbf) {
+		cfg |= CFG_NOSEC;
+	}
+	if (bloom.mask && (!p.secbf || rep.mask)) {
+		cfg |= CFG_POW2;
+	}
+	return cfg;
+}
 
 } // namespace nte

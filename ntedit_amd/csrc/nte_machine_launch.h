@@ -14,6 +14,7 @@ struct MachineArgs
 	const u32* lens;
 	u32 n_contigs;
 	const u64* bitmap;
+	const u64* runmap; // see EventEnv
 	const u64* events;
 	u64 n_events;
 	const u64* tabs;
@@ -55,16 +56,83 @@ struct MachineArgs
 	// counter (zeroed before the launch) -- event costs are heavy-tailed, a static split leaves most of
 	// the chip waiting for the unluckiest worker
 	u32* work_counter;
+	u32 cfg; // which instantiation runs it (machine_cfg_pick; 0 = the general one)
 };
 
 constexpr int MACHINE_TPB = 256;
 
+// k_assess (nte_assess.hip): the run map of the positions [pos_begin, pos_end) of the batch, pos_begin a multiple of
+// the tile (assess_tile()), n_tiles = tiles of that range
+struct AssessArgs
+{
+	const u8* seq;
+	u64 n_bytes;
+	const u64* bitmap;
+	u64* runmap;
+	const u64* tabs;
+	DevParams p;
+	Filter bloom, rep;
+	u64 pos_begin, pos_end, n_tiles;
+};
+void launch_k_assess(unsigned blocks, hipStream_t stream, const AssessArgs& a);
+int assess_tile();
+
+// The kernels exist once per machine configuration (MachineCfg bits; nte_machine_thread.hip / nte_machine_wave.hip are
+// compiled with -DNTE_CFG=<bits>): 0 = any configuration, 11 = -m 0 without -a, plain power-of-two filters (a secondary
+// filter allowed), 15 = the same without a secondary filter.
+#define NTE_MACHINE_CFGS(X) X(0) X(11) X(15)
+#define NTE_DECL_MACHINE(C)                                                                                              \
+	void launch_k_machine_thread_cfg##C(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);     \
+	void launch_k_machine_wave_cfg##C(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);       \
+	void machine_wave_profile_cfg##C(unsigned long long out[64]);
+NTE_MACHINE_CFGS(NTE_DECL_MACHINE)
+#undef NTE_DECL_MACHINE
+
+// the instantiation a launch uses: the most specific one its configuration allows
+inline u32
+machine_cfg_pick(const MachineArgs& a)
+{
+	const u32 cfg = machine_cfg_of(a.p, a.bloom, a.rep);
+	return (cfg & 15u) == 15u ? 15u : (cfg & 11u) == 11u ? 11u : 0u;
+}
+
 // one thread per event (pass 1 / single pass)
-void launch_k_machine_thread(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);
+inline void
+launch_k_machine_thread(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a)
+{
+	switch (a.cfg) {
+#define NTE_CASE(C) case C: launch_k_machine_thread_cfg##C(blocks, dyn_lds, stream, a); break;
+		NTE_MACHINE_CFGS(NTE_CASE)
+#undef NTE_CASE
+	default: launch_k_machine_thread_cfg0(blocks, dyn_lds, stream, a);
+	}
+}
+
 // one wavefront per event (sweep-only second pass)
-void launch_k_machine_wave(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);
+inline void
+launch_k_machine_wave(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a)
+{
+	switch (a.cfg) {
+#define NTE_CASE(C) case C: launch_k_machine_wave_cfg##C(blocks, dyn_lds, stream, a); break;
+		NTE_MACHINE_CFGS(NTE_CASE)
+#undef NTE_CASE
+	default: launch_k_machine_wave_cfg0(blocks, dyn_lds, stream, a);
+	}
+}
+
 // lanes per event in that kernel (a 256-thread block runs 256 / group events at a time)
 int machine_wave_group();
-void machine_wave_profile(unsigned long long out[24]);
+
+inline void
+machine_wave_profile(unsigned long long out[64])
+{
+	for (int i = 0; i < 64; i++) {
+		out[i] = 0;
+	}
+	unsigned long long t[64];
+#define NTE_SUM(C) machine_wave_profile_cfg##C(t); for (int i = 0; i < 64; i++) { out[i] += t[i]; }
+	NTE_MACHINE_CFGS(NTE_SUM)
+#undef NTE_SUM
+}
 
 } // namespace nte

@@ -147,6 +147,8 @@ make_dev_params(
 		budget = 2 * g;
 	}
 	d.event_budget = budget;
+	d.lanes = 2;     // runs of failing positions one position per lane (nte_machine.h, run_lanes)
+	d.defer_run = 2; // ... from the third failing position of a clean run on
 	d.inline_tries = 8; // (3 Gbp bench, sweep launch at 64 lanes per event: 4 / 8 / 16 tries -> machine 47.8 / 47.2 / 47.6 ms)
 	for (uint32_t i = 0; i < nte::MAX_HASHES; i++) {
 		d.mul[i] = (uint64_t)i ^ ((uint64_t)k * nte::MULTISEED);

@@ -50,19 +50,40 @@ class Resolver
 		}
 		return true;
 	}
-	// after the events handed out last time were re-run (their records replaced): carry on
-	bool resume(std::vector<uint32_t>& rerun)
+	// after the events handed out last time were re-run (their records replaced): carry on.
+	// may_park: a re-run with a (larger) budget may have parked an event again -- it is handed out once more
+	bool resume(std::vector<uint32_t>& rerun, bool may_park = false)
 	{
 		std::vector<size_t> todo;
 		todo.swap(blocked_);
 		for (size_t i : todo) {
 			const nte::Item* h = header(i);
-			if (!h || (h->w[3] & nte::EV_UNFINISHED)) {
+			if (!h || ((h->w[3] & nte::EV_UNFINISHED) && !may_park)) {
 				return false; // the re-run must have completed the event
 			}
 			walk(i, rerun);
 		}
 		return true;
+	}
+	// Every parked event behind the points where the walk is waiting: the events a widened re-run takes on at once
+	// instead of one per contig and round (most of them speculation, as in the first launch).
+	void parked_behind(std::vector<uint32_t>& out) const
+	{
+		for (size_t b : blocked_) {
+			const uint32_t contig = header(b)->w[0];
+			for (size_t i = b; i < n_; i++) {
+				const nte::Item* h = header(i);
+				if (!h) {
+					continue;
+				}
+				if (h->w[0] != contig) {
+					break;
+				}
+				if (h->w[3] & nte::EV_UNFINISHED) {
+					out.push_back((uint32_t)i);
+				}
+			}
+		}
 	}
 
   private:
@@ -79,7 +100,7 @@ class Resolver
 	size_t walk(size_t i, std::vector<uint32_t>& rerun)
 	{
 		const uint32_t contig = header(i)->w[0];
-		uint32_t cover = 0;
+		uint32_t cover = 0; // (a blocked event that is walked again starts at or behind every earlier cover)
 		bool waiting = false;
 		for (; i < n_; i++) {
 			const nte::Item* h = header(i);

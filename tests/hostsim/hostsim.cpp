@@ -33,6 +33,35 @@ make_filter(const uint8_t* data, uint64_t nbytes, uint32_t hash_num, bool counti
 	return f;
 }
 
+// one event through one instantiation of the machine (lanes: the wavefront-per-event launch's run_lanes() path)
+struct MachineOut
+{
+	u32 flags, fc, raw_first, cover_end, nsize, nbase;
+	unsigned long long cycles;
+};
+
+template<u32 CFG>
+static MachineOut
+run_machine(const EventEnv& env, u32 start, bool lanes)
+{
+	MachineT<CFG> m(env);
+	MachineOut o;
+	o.cover_end = start;
+	const unsigned long long t0 = __builtin_ia32_rdtsc();
+	if (lanes) {
+		m.template run<true>(start, o.cover_end);
+	} else {
+		m.template run<false>(start, o.cover_end);
+	}
+	o.cycles = __builtin_ia32_rdtsc() - t0;
+	o.flags = m.flags;
+	o.raw_first = m.first_chunk;
+	o.fc = m.finish(start, o.cover_end);
+	o.nsize = m.nsize;
+	o.nbase = m.nbase;
+	return o;
+}
+
 // same contract as the screening kernel
 static void
 sim_screen(const u8* seq, u64 n, const Filter& f, const DevParams& p, const u64* tab, u64* bitmap)
@@ -50,6 +79,50 @@ sim_screen(const u8* seq, u64 n, const Filter& f, const DevParams& p, const u64*
 				u64 s = i + 1 - p.k;
 				bitmap[s >> 6] |= 1ULL << (s & 63);
 			}
+		}
+	}
+}
+
+// host twin of k_assess (nte_assess.hip): the run map = the absent bitmap minus the positions whose clean-state
+// assessment cannot do anything; the very function the kernel calls (Machine::assess_gate) on a window of one position
+static void
+sim_assess(const u8* seq, u64 n, const Filter& f, const Filter& fr, const DevParams& p, const u64* tab, const u64* bitmap, u64* runmap)
+{
+	const u32 K = p.k + p.max_deletions + 1;
+	std::vector<u8> win(p.k + K + 8);
+	EventEnv env;
+	memset(&env, 0, sizeof env);
+	env.seq = seq;
+	env.batch_end = seq + n;
+	env.bitmap = bitmap;
+	env.runmap = bitmap;
+	env.tab = tab;
+	env.p = &p;
+	env.bloom = f;
+	env.rep = fr;
+	env.win = win.data();
+	env.win_stride = 1;
+	env.wave_size = 1;
+	memcpy(runmap, bitmap, ((n + 63) / 64) * 8);
+	for (u64 g = 0; g < n; g++) {
+		if (!bit_absent(bitmap, g)) {
+			continue;
+		}
+		bool clear = g + p.k + K <= n;
+		for (u32 i = 0; clear && i < p.k + K; i++) {
+			const u8 code = char_code(seq[g + i]);
+			clear = code != CODE_BAD;
+			win[i] = code;
+		}
+		if (!clear) {
+			continue; // (a non-accepted character within reach: the bit stays)
+		}
+		MachineT<0> m(env);
+		m.win_off = 0;
+		m.win_ok = true;
+		m.hs = m.seed_from_window();
+		if (!m.assess_gate(g, seq[g + p.k - 1])) {
+			runmap[g >> 6] &= ~(1ULL << (g & 63));
 		}
 	}
 }
@@ -144,10 +217,24 @@ hostsim_polish(
 	std::vector<u64> bitmap((n + 63) / 64 + 1);
 	sim_screen((const u8*)bases, n, f, p, tab, bitmap.data());
 
+	// the run map (k_assess): by default where the GPU path computes one (HOSTSIM_ASSESS=0 / 1: never / always)
+	std::vector<u64> runmap_store;
+	const u64* runmap = bitmap.data();
+	{
+		bool assess = p.snv || counting != 0;
+		if (const char* it = getenv("HOSTSIM_ASSESS")) {
+			assess = atoi(it) != 0;
+		}
+		if (assess) {
+			runmap_store.assign(bitmap.size(), 0);
+			sim_assess((const u8*)bases, n, f, fr, p, tab, bitmap.data(), runmap_store.data());
+			runmap = runmap_store.data();
+		}
+	}
 	// event starts, in position order
 	std::vector<u64> events;
 	for (u64 g = 0; g < n; g++) {
-		if (is_event_start(bitmap.data(), g, p.start_grid)) {
+		if (is_event_start(runmap, g, p.start_grid)) {
 			events.push_back(g);
 		}
 	}
@@ -168,7 +255,7 @@ hostsim_polish(
 	std::vector<Node> nodes(p.node_window);
 	std::vector<u32> ov_pos(p.node_window);
 	std::vector<u8> ov_chr(p.node_window);
-	std::vector<u8> win(2 * p.k + p.max_deletions + 8 + 32);
+	std::vector<u8> win(2 * p.k + p.max_deletions + 8 + 32 + 64);
 	std::vector<u8> prev(p.node_window);
 	std::vector<int16_t> lps(p.node_window);
 	// contig of every event
@@ -191,6 +278,12 @@ hostsim_polish(
 		if (const char* it = getenv("HOSTSIM_INLINE_TRIES")) {
 			pe.inline_tries = (u32)atoi(it);
 		}
+		if (const char* it = getenv("HOSTSIM_LANES")) { // 0: position by position, 1: clean runs one position per lane, 2: (default) also behind substitutions
+			pe.lanes = (u32)atoi(it);
+		}
+		if (const char* it = getenv("HOSTSIM_DEFER_RUN")) {
+			pe.defer_run = (u32)atoi(it);
+		}
 		EventEnv env;
 		env.seq = (const u8*)bases + offsets[ci];
 		env.batch_end = (const u8*)bases + n;
@@ -198,6 +291,7 @@ hostsim_polish(
 		env.contig = ci;
 		env.gbase = offsets[ci];
 		env.bitmap = bitmap.data();
+		env.runmap = runmap;
 		env.tab = tab;
 		env.p = &pe;
 		env.bloom = f;
@@ -214,33 +308,33 @@ hostsim_polish(
 		env.arena_chunks = arena_chunks;
 		env.defer_sweeps = getenv("HOSTSIM_TWO_PASS") != nullptr;
 		env.wave_size = 1;
-		Machine m(env);
 		u32 start = (u32)(g - offsets[ci]);
-		u32 cover_end = start;
-		unsigned long long t0c = __builtin_ia32_rdtsc();
-		m.run(start, cover_end);
-		unsigned long long dtc = __builtin_ia32_rdtsc() - t0c;
-		if (getenv("HOSTSIM_HIST")) { fprintf(stderr, "EVT %u %u %llu %d\n", start, cover_end, dtc, (int)(m.first_chunk != NONE32)); }
-		if (m.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
-			overflow = true;
-			arena_full = arena_full || (m.flags & EV_ARENA_FULL);
+		// the instantiation of the machine the GPU path would launch for this configuration (HOSTSIM_CFG=0: the general one)
+		u32 cfg = machine_cfg_of(pe, f, fr);
+		cfg = (cfg & 15u) == 15u ? 15u : (cfg & 11u) == 11u ? 11u : 0u;
+		if (const char* it = getenv("HOSTSIM_CFG")) {
+			cfg = atoi(it) ? cfg : 0u;
 		}
-		if (m.flags & EV_DEFERRED) {
+		MachineOut o = cfg == 15 ? run_machine<15>(env, start, !env.defer_sweeps) : cfg == 11 ? run_machine<11>(env, start, !env.defer_sweeps) : run_machine<0>(env, start, !env.defer_sweeps);
+		if (getenv("HOSTSIM_HIST")) { fprintf(stderr, "EVT %u %u %llu %d\n", start, o.cover_end, o.cycles, (int)(o.raw_first != NONE32)); }
+		if (o.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
+			overflow = true;
+			arena_full = arena_full || (o.flags & EV_ARENA_FULL);
+		}
+		if (o.flags & EV_DEFERRED) {
 			// second pass: the same event again, sweeps allowed
 			env.defer_sweeps = false;
-			Machine m2(env);
-			cover_end = start;
-			m2.run(start, cover_end);
-			if (m2.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
+			o = cfg == 15 ? run_machine<15>(env, start, true) : cfg == 11 ? run_machine<11>(env, start, true) : run_machine<0>(env, start, true);
+			if (o.flags & (EV_OVERFLOW | EV_ARENA_FULL)) {
 				overflow = true;
-				arena_full = arena_full || (m2.flags & EV_ARENA_FULL);
+				arena_full = arena_full || (o.flags & EV_ARENA_FULL);
 			}
-			return m2.finish(start, cover_end);
+			return o.fc;
 		}
-		u32 fc = m.finish(start, cover_end);
+		u32 fc = o.fc;
 		if (getenv("HOSTSIM_DEBUG")) {
 			if (fc != NONE32) { const Item* c = arena.data() + (size_t)fc*CHUNK_ITEMS; for (u32 i=0;i<c[0].w[1];i++) fprintf(stderr,"   item %u: %08x %u %u %u\n", i, c[i].w[0], c[i].w[1], c[i].w[2], c[i].w[3]); }
-			fprintf(stderr, "event contig %u start %u cover_end %u flags %u first_chunk %d nsize %u nbase %u\n", ci, start, cover_end, m.flags, (int)fc, m.nsize, m.nbase);
+			fprintf(stderr, "event contig %u start %u cover_end %u flags %u first_chunk %d nsize %u nbase %u\n", ci, start, o.cover_end, o.flags, (int)fc, o.nsize, o.nbase);
 		}
 		return fc;
 	};
@@ -256,16 +350,24 @@ hostsim_polish(
 			return -7;
 		}
 		unsigned rounds = 0;
+		u32 wide_budget = p.event_budget ? p.event_budget : 1;
 		while (!rerun.empty() && !overflow) {
+			// (the plan of PolishRun::collect: one parked event per contig and round at first, then all of them with a growing budget)
+			const bool wide = rounds >= 6;
+			if (wide) {
+				rerun.clear();
+				rs.parked_behind(rerun);
+				wide_budget = wide_budget < (1u << 26) ? wide_budget * 16u : 0u;
+			}
 			for (u32 i : rerun) {
-				first_by_event[i] = run_event(i, 0);
+				first_by_event[i] = run_event(i, wide ? wide_budget : 0);
 			}
 			rerun.clear();
 			rounds++;
 			if (overflow) {
 				break; // a re-run ran out of arena / rope window: the whole batch again with more room (as the C ABI does)
 			}
-			if (!rs.resume(rerun)) {
+			if (!rs.resume(rerun, wide)) {
 				return -7;
 			}
 		}
@@ -279,8 +381,8 @@ hostsim_polish(
 	}
 	} // attempt
 	if (getenv("HOSTSIM_COUNTERS")) {
-		fprintf(stderr, "COUNTERS events %zu probes %llu slow_rolls %llu ins_cands %llu del_cands %llu sweeps %llu\n",
-		        events.size(), g_wc.probes, g_wc.slow_rolls, g_wc.ins_cands, g_wc.del_cands, g_wc.sweeps);
+		fprintf(stderr, "COUNTERS events %zu probes %llu slow_rolls %llu ins_cands %llu del_cands %llu sweeps %llu lane_batches %llu lane_positions %llu lane_walked %llu lane_edits %llu\n",
+		        events.size(), g_wc.probes, g_wc.slow_rolls, g_wc.ins_cands, g_wc.del_cands, g_wc.sweeps, g_wc.lane_batches, g_wc.lane_positions, g_wc.lane_walked, g_wc.lane_edits);
 	}
 	if (overflow) {
 		return NTEDIT_E_OVERFLOW;

@@ -124,7 +124,7 @@ def main():
                     cmd[cmd.index("-f") + 1] = case["draft"] + ".bgz"
                 # the L2-partitioned screening pipeline on small inputs, in several record chunks
                 if rng.random() < 0.35:
-                    cmd += ["--tune", "screen_mode=2", "--tune", "bin_chunk=%d" % int(rng.choice([12288, 3 * 12288, 1 << 20]))]
+                    cmd += ["--tune", "screen_mode=2", "--tune", "bin_chunk=%d" % int(rng.choice([16384, 3 * 16384, 1 << 20]))]
                     if rng.random() < 0.3:
                         cmd += ["--tune", "bin_cap_percent=%d" % int(rng.choice([10, 60, 90]))]
                     if rng.random() < 0.3:
@@ -146,6 +146,15 @@ def main():
                 if r.returncode != 0:
                     why = "ntedit exit %d: %s" % (r.returncode, r.stderr[-300:])
             else:
+                # launch scheme of the host build: one pass / the two passes of the GPU path, runs of failing
+                # positions one per "lane" or position by position, hand-over threshold of the first pass
+                for key, val in (("HOSTSIM_TWO_PASS", rng.choice(["", "1"])), ("HOSTSIM_LANES", rng.choice(["0", "1", "2", "2"])),
+                                 ("HOSTSIM_DEFER_RUN", rng.choice(["0", "1", "2", "5"])),
+                                 ("HOSTSIM_ASSESS", rng.choice(["", "", "0", "1"])), ("HOSTSIM_CFG", rng.choice(["", "", "0"]))):
+                    if val:
+                        os.environ[key] = str(val)
+                    else:
+                        os.environ.pop(key, None)
                 rep = H.load_bf(case["rep"]) if case["rep"] else None
                 bf = H.load_bf(case["bf"])
                 recs = H.read_fasta(case["draft"])

@@ -17,9 +17,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 CASES = [
     # name, make_case kwargs, tunings
     ("small_pow2", dict(bfbytes=1 << 17, n=60000), {}),
-    ("one_slice_forced_chunks", dict(bfbytes=1 << 17, n=60000), {"bin_chunk": 3 * 12288}),
+    ("one_slice_forced_chunks", dict(bfbytes=1 << 17, n=60000), {"bin_chunk": 3 * 16384}),
     ("many_slices", dict(bfbytes=1 << 27, n=150000, flavor="N rep"), {}),
-    ("nonpow2", dict(bfbytes=100000007 * 8, n=150000, flavor="N rep"), {"bin_chunk": 5 * 12288}),
+    ("nonpow2", dict(bfbytes=100000007 * 8, n=150000, flavor="N rep"), {"bin_chunk": 5 * 16384}),
     ("h1", dict(bfbytes=1 << 22, n=100000, hashes=1), {}),
     ("h5_k40", dict(bfbytes=1 << 24, n=100000, hashes=5, k=40), {}),
     ("force_xcc", dict(bfbytes=1 << 27, n=120000), {"force_xcc": 4}),

@@ -626,6 +626,9 @@ def main():
                             (", SNV mode (-s 1, -i 0 -d 0)" if args.snv else "") +
                             (", COUNTING filter (8-bit counters, synthetic contents 1..4, -p 2)" if args.counting else ""),
                 "total_bases": total_bases,
+                "workload_bytes": int(my_bytes),  # (batch bytes of this rank: what the counter records under profiles/ are keyed by)
+                "k": args.k, "hashes": args.hashes, "filter_bytes": args.filter_bytes,
+                "snv": bool(args.snv), "counting": bool(args.counting),
                 "parallelism": "ONE draft sharded over %d rank(s) by bases (LPT over pieces; %d contig(s) cut into "
                                "segments), filter broadcast once over RCCL (untimed)" % (world, n_cut),
                 "shard_bases": shard_bases,
@@ -657,17 +660,28 @@ def main():
         }
         if weak is not None:
             out["weak"] = weak
+        # what the library's kernels were built from: counter records kept under profiles/ are quoted for this build only
+        try:
+            from ntedit_amd import _lib as _L
+            build_id = _L.load().ntedit_hip_build_id().decode()
+        except Exception:
+            build_id = None
+        out["build_id"] = build_id
         # HBM traffic of the dominant kernel's launches from the committed PMC run (bench.py cannot collect counters
-        # itself); only quoted when it was taken on this exact workload
+        # itself); only quoted when it was taken on this exact workload AND this exact build of the kernels
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
             kk = [k for k in tr["kernels"] if k.split("<")[0] == dom_kernel]
             if int(tr["workload_bytes"]) == int(my_bytes) and args.hashes == 3 and kk and \
                     int(tr["kernels"][kk[0]]["launches"]) % launches[0] == 0:
-                e = tr["kernels"][kk[0]]
-                out["roofline"]["traffic"] = int(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"])
-                out["roofline"]["traffic_source"] = tr["source"]
-                out["roofline"]["l2_hit_rate"] = round(e["tcc_hit_rate"], 4) if e.get("tcc_hit_rate") is not None else None
+                if build_id is not None and tr.get("build_id") == build_id:
+                    e = tr["kernels"][kk[0]]
+                    out["roofline"]["traffic"] = int(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"])
+                    out["roofline"]["traffic_source"] = tr["source"]
+                    out["roofline"]["l2_hit_rate"] = round(e["tcc_hit_rate"], 4) if e.get("tcc_hit_rate") is not None else None
+                else:
+                    out["roofline"]["traffic_source"] = ("none: profiles/roofline_traffic.json was taken on build %s, this is %s"
+                                                         % (tr.get("build_id"), build_id))
         except Exception:
             pass
         if last is not None:
@@ -677,6 +691,7 @@ def main():
             out["events"] = {"absent_kmers": int(last.absent_kmers), "event_starts": int(last.events),
                              "skipped_as_overtaken": int(last.events_skipped),
                              "deferred_to_sweep_pass": int(last.events_deferred)}
+        pps = None
         if not args.no_gather:
             try:
                 pps, gms = pol.gather_bench(args.filter_bytes if args.filter_bytes & (args.filter_bytes - 1) == 0
@@ -685,6 +700,31 @@ def main():
                 out["roofline"]["frac_of_random_gather"] = round(out["roofline"]["probes_per_s"] / pps, 4)
             except Exception as e:  # pragma: no cover
                 out["roofline"]["random_gather_error"] = str(e)
+        # the edit search ("report probes/s only"): filter bytes gathered by the event-machine launches of one
+        # step, counted lane by lane by the profile build (`make profile`, tools/gpu_machine_probes.sh) on this workload
+        # and this build of the kernels, over the machine time of THIS run
+        if last is not None and not args.screen_only:
+            m_ms = sum(machine_ms) / len(machine_ms)
+            mach = {"ms": round(m_ms, 3), "probes": None, "probes_per_s": None, "frac_of_random_gather": None}
+            try:
+                mp = json.load(open(os.path.join(ROOT, "profiles", "machine_probes.json")))
+                want = {"workload_bytes": int(my_bytes), "k": args.k, "hashes": args.hashes, "filter_bytes": args.filter_bytes,
+                        "snv": bool(args.snv), "counting": bool(args.counting)}
+                rec = [r for r in mp["records"] if all(r.get(k2) == v for k2, v in want.items())]
+                if rec and build_id is not None and rec[-1].get("build_id") == build_id:
+                    r = rec[-1]
+                    mach["probes"] = int(r["gathers_thread_launches"] + r["gathers_wave_launches"])
+                    mach["probes_thread_launches"] = int(r["gathers_thread_launches"])
+                    mach["probes_wave_launches"] = int(r["gathers_wave_launches"])
+                    mach["probes_per_s"] = round(mach["probes"] / (m_ms * 1e-3), 0)
+                    if pps:
+                        mach["frac_of_random_gather"] = round(mach["probes_per_s"] / pps, 4)
+                    mach["source"] = mp.get("source")
+                elif rec:
+                    mach["source"] = "none: profiles/machine_probes.json was taken on build %s, this is %s" % (rec[-1].get("build_id"), build_id)
+            except Exception:
+                pass
+            out["roofline"]["machine"] = mach
         if world == 1 and not args.no_regions and not args.screen_only:
             out.update(measured_regions(job, pol, args))
         if world == 1 and not args.no_cpu_baseline:

@@ -361,6 +361,11 @@ void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
  * NTEDIT_HIP_NO_BIND (see ntedit_hip_bind_near_device). */
 int ntedit_hip_set_tuning(ntedit_hip_ctx* ctx, const char* key, uint64_t value);
 
+/* Identifies what the library's kernels were built from (a hash of the device-side sources, set by the Makefile):
+ * bench.py stamps the counter records it keeps under profiles/ with it and quotes them only for the same build.
+ * No counterpart in the reference. */
+const char* ntedit_hip_build_id(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2107,6 +2107,10 @@ PolishRun::run_chunk_events(size_t j)
 		    (unsigned long long)(rounds ? (u64)n32 - n_A - n_B - n_C : 0), n_def, p_all, p2_ms, h_tail[0], status, c->dp.node_window);
 		unsigned long long pr[64];
 		machine_wave_profile(pr);
+		const unsigned long long tg = machine_thread_gathers();
+		if (pr[15] || tg) {
+			fprintf(stderr, "[ntedit_hip] machine filter gathers (profile build): thread-per-event launches %llu, wavefront-per-event launches %llu\n", tg, pr[15]);
+		}
 		if (pr[8]) {
 			fprintf(stderr, "[ntedit_hip] wave-kernel events by duration (log2 cycles: count):");
 			for (int b = 0; b < 32; b++) {
@@ -2345,8 +2349,13 @@ ntedit_hip_polish_batch(
 			if ((rc = bin_records_lost(c, &lost))) {
 				return run.bail(rc);
 			}
-			if (lost && attempt < 4) {
-				continue; // (the context screens with the direct kernel now)
+			if (lost) {
+				// the bitmap of this attempt is void; the context screens with the direct kernel from now on.  (The loss
+				// is deterministic and shows on the first attempt; a later one is out of retries rather than trusted.)
+				if (attempt >= 4) {
+					return run.bail(fail(c, NTEDIT_E_OVERFLOW, "the screening lost probe records and no retry is left"));
+				}
+				continue;
 			}
 		}
 		if (run.status == 0) {
@@ -2750,6 +2759,15 @@ float
 ntedit_hip_last_kernel_ms(const ntedit_hip_ctx* c)
 {
 	return c ? c->last_ms : 0.f;
+}
+
+#ifndef NTE_BUILD_ID
+#define NTE_BUILD_ID "unknown"
+#endif
+const char*
+ntedit_hip_build_id(void)
+{
+	return NTE_BUILD_ID;
 }
 
 int

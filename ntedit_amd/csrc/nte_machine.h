@@ -48,6 +48,7 @@ static __device__ unsigned long long g_prof[64]; // (one per translation unit: t
 #define NTE_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_t0 = prof_t, prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
 #define NTE_PROF_COUNT(slot) (prof_cnt[slot]++)
 #define NTE_PROF_ADD(slot, n) (prof_cnt[slot] += (n))
+#define NTE_GATHER(n) (prof_gathers += (n)) // filter bytes gathered by this lane (the edit search's probes)
 #define NTE_PROF(slot)                                                    \
 	do {                                                                  \
 		const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
@@ -62,6 +63,9 @@ static __device__ unsigned long long g_prof[64]; // (one per translation unit: t
 	} while (0)
 #define NTE_PROF_FLUSH                                                    \
 	do {                                                                  \
+		if (prof_gathers) {                                               \
+			atomicAdd(&g_prof[15], prof_gathers); /* (every lane its own) */ \
+		}                                                                 \
 		if ((threadIdx.x & (e.wave_size - 1u)) == 0) {                    \
 			for (int i_ = 0; i_ < 8; i_++) {                              \
 				atomicAdd(&g_prof[i_], prof_acc[i_]);                     \
@@ -83,6 +87,7 @@ static __device__ unsigned long long g_prof[64]; // (one per translation unit: t
 #define NTE_PROF_DECL ((void)0)
 #define NTE_PROF_COUNT(slot) ((void)0)
 #define NTE_PROF_ADD(slot, n) ((void)0)
+#define NTE_GATHER(n) ((void)0)
 #define NTE_PROF(slot) ((void)0)
 #define NTE_PROF_SUB(slot) ((void)0)
 #define NTE_PROF_FLUSH ((void)0)
@@ -191,6 +196,7 @@ struct MachineT
 		u32 mn = 255;
 		for (unsigned i = 0; i < f.hash_num; i++) {
 			const u32 c = f.data[slot(f, hash_extend(base, p, i))];
+			NTE_GATHER(1);
 			mn = c < mn ? c : mn;
 			if (mn == 0) {
 				break;
@@ -208,6 +214,7 @@ struct MachineT
 		}
 		for (unsigned i = 0; i < f.hash_num; i++) {
 			const u64 n = slot(f, hash_extend(base, p, i));
+			NTE_GATHER(1);
 			if (!((f.data[n >> 3] >> (n & 7)) & 1)) {
 				return false;
 			}
@@ -241,7 +248,7 @@ struct MachineT
 	bool changed_seq; // the last failing position applied an edit (else the sequence, and the look-ahead, still stand)
 	bool la_win;      // the character window is still the one the look-ahead was hashed from (the stride needs it)
 #if defined(NTE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-	unsigned long long prof_sub_t = 0, prof_sub[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, prof_cnt[4] = { 0, 0, 0, 0 };
+	mutable unsigned long long prof_sub_t = 0, prof_sub[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, prof_cnt[4] = { 0, 0, 0, 0 }, prof_gathers = 0;
 #endif
 
 	NTE_HD
@@ -436,7 +443,8 @@ struct MachineT
 				flags |= EV_OVERFLOW;
 			}
 		}
-		if (n_ov + 8 > p.node_window) {
+		// (every read of a draft character scans the overlay: entries behind the head cursor go as soon as there are a few)
+		if (n_ov >= 48 || n_ov + 8 > p.node_window) {
 			u32 w = 0;
 			for (u32 i = 0; i < n_ov; i++) {
 				if (e.ov_pos[i] >= h_seq_i) {
@@ -653,6 +661,7 @@ struct MachineT
 					byte[i] = 255;
 					if ((alive >> i) & 1) {
 						byte[i] = f.data[slot(f, hash_extend(b[i], p, h))];
+						NTE_GATHER(1);
 					}
 				}
 				NTE_UNROLL
@@ -681,6 +690,7 @@ struct MachineT
 				sh[i] = 0;
 				if ((alive >> i) & 1) {
 					const u64 sl = slot(f, hash_extend(b[i], p, h));
+					NTE_GATHER(1);
 					byte[i] = f.data[sl >> 3];
 					sh[i] = (u8)(sl & 7);
 				}
@@ -1499,6 +1509,77 @@ struct MachineT
 		return 0;
 	}
 
+	// scratch byte t of the sweep below: the KMP table and the previous-insertion string are idle during a sweep
+	// (3 x node_window >= 504 bytes; a sweep has at most 341 + 10 tries)
+	NTE_HD u8&
+	sweep_byte(u32 t) const
+	{
+		const u32 w2 = 2 * p.node_window;
+		return t < w2 ? reinterpret_cast<u8*>(e.lps)[t] : e.prev[t - w2];
+	}
+
+	// Modes 1 and 2 (the best candidate wins, ntedit.cpp:1587-1744), with the character window: the support of EVERY
+	// try of the list (see try_indels_first_accepted for its order) is computed first -- try t by lane t % wave_size --
+	// and then the reference's running best ("a try that reaches the bar and is at least as good as the best so far takes
+	// over, the support it displaces becomes the alternate") is replayed over the supports in list order.
+	NTE_HD bool
+	try_indels_all(u8 draft_char, u8 index_char, u32& num_deletions, Best& b)
+	{
+		const u32 W = e.wave_size;
+		const u32 lane = wave_lane();
+		const u8 draft_code = char_code(draft_char);
+		const u32 nd0 = num_deletions;
+		u32 D = nd0 <= p.max_deletions ? p.max_deletions - nd0 + 1 : 0;
+		if (D > p.ins_tries) {
+			D = p.ins_tries;
+		}
+		const u32 total = p.ins_tries + D;
+		for (u32 t = lane; t < total; t += W) {
+			u32 support = 0;
+			if (t < 2 * D && (t & 1)) {
+				support = fast_deletion_support(draft_code, nd0 + (t >> 1));
+			} else {
+				u8 ins[12];
+				const u32 m = insertion_candidate(index_char, t < 2 * D ? (t >> 1) : t - D, ins);
+				const u32 cp = fast_insertion_support(draft_code, ins, m);
+				support = cp >= p.thr_edit ? cp : 0;
+			}
+			sweep_byte(t) = (u8)(support < 255 ? support : 255); // (a support is at most k <= 200)
+		}
+		lanes_sync();
+		u32 best_support = 0, alt_support = 0, best_t = 0;
+		for (u32 t = 0; t < total; t++) {
+			const u32 s = sweep_byte(t);
+			if (s && s >= best_support) {
+				if (best_support) {
+					alt_support = best_support;
+				}
+				best_support = s;
+				best_t = t;
+			}
+		}
+		lanes_sync(); // (the scratch goes back to its owners)
+		num_deletions = nd0 + D;
+		if (best_support == 0) {
+			return false;
+		}
+		if ((mode() == 2 && best_support > b.num_support) || mode() == 1) {
+			if (best_t < 2 * D && (best_t & 1)) {
+				b.edit_type = 3;
+				b.n_indel = nd0 + (best_t >> 1);
+				for (u32 i = 0; i < b.n_indel && i < 12; i++) {
+					b.indel[i] = 0; // only the length of a deletion is consumed
+				}
+			} else {
+				b.edit_type = 2;
+				b.n_indel = insertion_candidate(index_char, best_t < 2 * D ? (best_t >> 1) : best_t - D, b.indel);
+			}
+			b.num_support = best_support;
+			b.altsupp1 = alt_support;
+		}
+		return true;
+	}
+
 	// ntedit.cpp:1548-1744
 	NTE_HD bool
 	try_indels(u8 draft_char, u8 index_char, u32& num_deletions, Best& b)
@@ -1506,6 +1587,9 @@ struct MachineT
 		NTE_COUNT(sweeps, 1);
 		if (mode() == 0 && win_ok) {
 			return try_indels_first_accepted(draft_char, index_char, num_deletions, b) > 0;
+		}
+		if (win_ok && p.ins_tries + p.max_deletions + 1 <= 3 * p.node_window) {
+			return try_indels_all(draft_char, index_char, num_deletions, b);
 		}
 		u32 temp_best_support = 0, temp_alt_support = 0;
 		u8 temp_best_indel[12];
@@ -2573,6 +2657,7 @@ struct MachineT
 				byte[i] = 255;
 				if ((alive >> i) & 1) {
 					byte[i] = f.data[slot(f, hash_extend(b[i], p, h))];
+					NTE_GATHER(1);
 				}
 			}
 			NTE_UNROLL

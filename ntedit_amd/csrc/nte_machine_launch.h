@@ -84,7 +84,8 @@ int assess_tile();
 #define NTE_DECL_MACHINE(C)                                                                                              \
 	void launch_k_machine_thread_cfg##C(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);     \
 	void launch_k_machine_wave_cfg##C(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);       \
-	void machine_wave_profile_cfg##C(unsigned long long out[64]);
+	void machine_wave_profile_cfg##C(unsigned long long out[64]);                                                       \
+	unsigned long long machine_thread_gathers_cfg##C();
 NTE_MACHINE_CFGS(NTE_DECL_MACHINE)
 #undef NTE_DECL_MACHINE
 
@@ -122,6 +123,16 @@ launch_k_machine_wave(unsigned blocks, size_t dyn_lds, hipStream_t stream, const
 
 // lanes per event in that kernel (a 256-thread block runs 256 / group events at a time)
 int machine_wave_group();
+
+inline unsigned long long
+machine_thread_gathers()
+{
+	unsigned long long v = 0;
+#define NTE_SUM(C) v += machine_thread_gathers_cfg##C();
+	NTE_MACHINE_CFGS(NTE_SUM)
+#undef NTE_SUM
+	return v;
+}
 
 inline void
 machine_wave_profile(unsigned long long out[64])

@@ -44,7 +44,10 @@ ntedit_hip_fasta_load(const char* path, uint64_t min_len, unsigned threads, nted
 		threads = std::thread::hardware_concurrency();
 		threads = threads > 16 ? 16 : (threads < 1 ? 1 : threads);
 	}
-	ntedit_hip_fasta* f = new ntedit_hip_fasta();
+	// (multi-GB containers are filled below: an exception must not cross the C ABI)
+	ntedit_hip_fasta* f = nullptr;
+	try {
+	f = new ntedit_hip_fasta();
 	nte_host::FastaMap fmap(path, threads, threads > 64 ? 64 : threads);
 	if (fmap.ok()) {
 		const size_t N = fmap.records();
@@ -99,6 +102,19 @@ ntedit_hip_fasta_load(const char* path, uint64_t min_len, unsigned threads, nted
 			delete f;
 			return NTEDIT_E_IO;
 		}
+	}
+	} catch (const std::bad_alloc&) {
+		delete f;
+		set_err(err, errcap, std::string("`") + path + "': out of memory while loading the draft");
+		return NTEDIT_E_IO;
+	} catch (const std::exception& ex) {
+		delete f;
+		set_err(err, errcap, std::string("`") + path + "': " + ex.what());
+		return NTEDIT_E_IO;
+	} catch (...) {
+		delete f;
+		set_err(err, errcap, std::string("`") + path + "': unexpected failure while loading the draft");
+		return NTEDIT_E_IO;
 	}
 	*out = f;
 	return 0;

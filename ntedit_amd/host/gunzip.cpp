@@ -346,6 +346,39 @@ Gunzip::refill_()
 	nbits_ |= 56;
 }
 
+// a larger input buffer with more of the file in it (parse_header_: a header field longer than the buffer)
+bool
+Gunzip::grow_input_()
+{
+	const size_t off = (size_t)(in_ - inbuf_), have0 = (size_t)(in_end_ - inbuf_);
+	const size_t ns = inbuf_size_ * 2;
+	unsigned char* nb = (unsigned char*)realloc(inbuf_, ns + INPAD);
+	if (!nb) {
+		return fail_("out of memory");
+	}
+	inbuf_ = nb;
+	inbuf_size_ = ns;
+	size_t have = have0;
+	while (have < inbuf_size_) {
+		const ssize_t r = ::read(fd_, inbuf_ + have, inbuf_size_ - have);
+		if (r < 0) {
+			if (errno == EINTR) {
+				continue;
+			}
+			return fail_("read error");
+		}
+		if (r == 0) {
+			file_eof_ = true;
+			break;
+		}
+		have += (size_t)r;
+	}
+	in_ = inbuf_ + off;
+	in_end_ = inbuf_ + have;
+	memset(inbuf_ + have, 0, INPAD);
+	return true;
+}
+
 // RFC 1952 member header.  At the end of the file, or at bytes that do not start another member (zlib's gzread
 // ignores those), the stream is over.
 bool
@@ -359,10 +392,17 @@ Gunzip::parse_header_()
 		stage_ = ST_END;
 		return true;
 	}
+	// A header field (FEXTRA, FNAME, FCOMMENT) may be longer than what is buffered: gzread takes any length, so the
+	// parse is repeated with more of the file until it is complete or the file is over.
 	const unsigned char* p = in_;
+	for (;;) {
+	p = in_;
 	const unsigned char* const e = in_end_;
-	if (av < 10) {
-		return fail_("unexpected end of file");
+	bool short_of_input = false;
+	do {
+	if ((size_t)(e - p) < 10) {
+		short_of_input = true;
+		break;
 	}
 	if (p[0] != 0x1f || p[1] != 0x8b) {
 		return fail_("incorrect header check");
@@ -377,12 +417,14 @@ Gunzip::parse_header_()
 	p += 10;
 	if (flg & 4) {
 		if (e - p < 2) {
-			return fail_("unexpected end of file");
+			short_of_input = true;
+			break;
 		}
 		const size_t xlen = p[0] | ((size_t)p[1] << 8);
 		p += 2;
 		if ((size_t)(e - p) < xlen) {
-			return fail_("unexpected end of file");
+			short_of_input = true;
+			break;
 		}
 		p += xlen;
 	}
@@ -390,16 +432,29 @@ Gunzip::parse_header_()
 		if (flg & bit) {
 			const void* z = memchr(p, 0, (size_t)(e - p));
 			if (!z) {
-				return fail_("unexpected end of file");
+				short_of_input = true;
+			break;
 			}
 			p = (const unsigned char*)z + 1;
 		}
 	}
 	if (flg & 2) {
 		if (e - p < 2) {
-			return fail_("unexpected end of file");
+			short_of_input = true;
+			break;
 		}
 		p += 2; // (header CRC: not checked, as zlib's gzread does not either)
+	}
+	} while (false);
+	if (!short_of_input) {
+		break;
+	}
+	if (file_eof_) {
+		return fail_("unexpected end of file");
+	}
+	if (!grow_input_()) {
+		return false;
+	}
 	}
 	in_ = p;
 	bits_ = 0;

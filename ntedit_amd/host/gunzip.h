@@ -55,6 +55,7 @@ class Gunzip
 		ST_END
 	};
 	bool fill_input_();
+	bool grow_input_();
 	bool fail_(const char* what);
 	bool parse_header_();
 	bool parse_block_();

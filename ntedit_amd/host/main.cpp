@@ -60,7 +60,8 @@ static const char USAGE[] = PROGRAM
     "	-p,	minimum k-mer coverage threshold (CBF only) [default=1]\n"
     "	-q,	maximum k-mer coverage threshold (CBF only) [default=255]\n"
     "	--gpu N,	HIP device index [default=0]\n"
-    "	--batch-bases N,	bases per GPU batch [default=1073741824]\n"
+    "	--batch-bases N,	bases per GPU batch [default: the first batch 134217728, doubling up to 536870912]\n"
+    "	--tune KEY=VALUE,	library tuning knob (ntedit_hip_set_tuning; repeatable; none of them changes a result)\n"
     "	--shard I/N,	polish share I of N of the contigs, split by BASES (greedy longest-first over whole contigs, the\n"
     "			same on every process); writes <prefix>.index.tsv for `python -m ntedit_amd.merge`.\n"
     "			(`python -m ntedit_amd.run` is the full multi-GPU driver: one filter broadcast, large contigs cut)\n"
@@ -349,7 +350,17 @@ main(int argc, char** argv)
 				fprintf(stderr, PROGRAM ": invalid option: `--tune %s'\n", optarg);
 				exit(EXIT_FAILURE);
 			}
-			tunes.emplace_back(std::string(optarg, eq - optarg), strtoull(eq + 1, nullptr, 10));
+			// (the value through the option parser: trailing garbage is an error, not a silent 0)
+			unsigned long long tv = 0;
+			{
+				std::istringstream ss(eq + 1);
+				ss >> tv;
+				if (!ss.eof() || ss.fail() || eq[1] == '-') {
+					fprintf(stderr, PROGRAM ": invalid option: `--tune %s'\n", optarg);
+					exit(EXIT_FAILURE);
+				}
+			}
+			tunes.emplace_back(std::string(optarg, eq - optarg), tv);
 			break;
 		}
 		case OPT_HELP:

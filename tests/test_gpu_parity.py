@@ -618,6 +618,37 @@ def test_make_genome_bf_cli(tmp_path, oracle_build):
     assert subprocess.run([tool, "--genome", str(tmp_path / "g1.fa")], capture_output=True).returncode == 1
 
 
+def test_parked_events_resolve_quickly(tmp_path, oracle_build):
+    """Nearly every event parked by a tiny budget on a draft where hardly a k-mer is in the filter (the regime of fuzz seed
+    42424200091: k=128, 1.7 % errors, budget 8; a third of its length here).  What the serial order applies there is ONE
+    event per contig that never gets back to a clean state -- the reference's serial program itself, run by one
+    wavefront -- so the time is that chain's, not the number of re-run rounds (1; PolishRun::collect widens the re-runs
+    after 6).  Modes 1 / 2 evaluate a sweep's candidates across the lanes (try_indels_all), the overlay of changed draft
+    characters is pruned behind the head cursor as it grows: the full-length case took 8 minutes and takes 13 s / 40 s
+    (-m 0 / -m 1 -a 1); byte-identical."""
+    import time
+    case_kw = {'n': 14000, 'contigs': 3, 'k': 128, 'hashes': 2, 'p_sub': 0.01, 'p_ins': 0.005, 'p_del': 0.002,
+               'flavor': 'lower sec', 'bfbytes': 131072}
+    base = {'mode': 1, 'mask': 1, 'jump': 2, 'max_insertions': 5, 'max_deletions': 5, 'min_contig_len': 0,
+            'missing_threshold': 9.0, 'edit_threshold': 25.0, 'start_grid': 16, 'event_budget': 8}
+    case = H.make_case(str(tmp_path), 42424200091, **case_kw)
+    for par_kw in (base, dict(base, mode=0, mask=0)):
+        hp = H.default_params(**par_kw)
+        H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), case["rep"])
+        pol = _fresh(force_rounds=False)
+        try:
+            _load_filters(pol, case)
+            pol.set_params(_hip_params(**par_kw))
+            t0 = time.time()
+            pol.polish_records(H.read_fasta(case["draft"]), str(tmp_path / "g"))
+            dt = time.time() - t0
+        finally:
+            pol.close()
+        for suf in ("_changes.tsv", "_edited.fa"):
+            assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("g" + suf)), shallow=False), (suf, par_kw)
+        assert dt < 20.0, "the serial chains took %.1f s (%r)" % (dt, par_kw)
+
+
 @pytest.mark.parametrize("kw", [dict(snv=1, mask=1), dict(mask=1), dict(snv=1, mode=2)])
 def test_last_kmer_is_never_a_seed_gpu(tmp_path, oracle_build, kw):
     case = H.make_tail_case(str(tmp_path))

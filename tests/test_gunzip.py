@@ -122,6 +122,17 @@ def test_gunzip_header_fields_and_members(tmp_path):
         for block in (1 << 20, 1000):
             rc, got = gunzip(p, tmp_path, block)
             assert rc == len(got) and got == a + b + c + a, (tail[:8], block, rc)
+    # header fields longer than the decoder's input buffer (2 KB here): gzread takes any length
+    long_blob = member(c, 4 | 8 | 16, extra=b"\x01" * 60000, name=b"n" * 9000, comment=b"c" * 70000) + member(a, 8, name=b"y" * 300000)
+    assert gzip.decompress(long_blob) == c + a
+    with open(p, "wb") as f:
+        f.write(long_blob)
+    for in_bytes in (2048, 4096, 0):
+        rc, got = gunzip(p, tmp_path, 1 << 20, in_bytes)
+        assert rc == len(got) and got == c + a, in_bytes
+    with open(p, "wb") as f:
+        f.write(long_blob[:len(long_blob) // 2 + 40000][:len(member(c, 4 | 8 | 16, extra=b"\x01" * 60000, name=b"n" * 9000, comment=b"c" * 70000)) + 200000])
+    assert gunzip(p, tmp_path, 1 << 20, 2048)[0] == -3  # (the file ends inside the second member's name)
     # the second member starts, and the file ends inside its header / its data / its trailer
     full = member(a) + member(c)
     for cut in (len(member(a)) + 2, len(member(a)) + 9, len(full) - 9, len(full) - 8, len(full) - 1):

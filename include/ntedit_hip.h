@@ -126,7 +126,26 @@ int ntedit_hip_set_params(ntedit_hip_ctx* ctx, const ntedit_hip_params* p);
  * Batch layout: `bases` holds the contigs of the batch; contig i occupies
  * bases[offsets[i] .. offsets[i]+lens[i]) and every contig is followed by at
  * least one byte that is not an accepted base (the host driver uses '\n').
- * n = total bytes.  on_device != 0 means `bases` is already in HBM. */
+ * n = total bytes.  on_device: NTEDIT_HIP_BASES_HOST (0) `bases` is host memory, NTEDIT_HIP_BASES_DEVICE (1) it is
+ * already in HBM, NTEDIT_HIP_BASES_PACKED (2; ntedit_hip_polish_batch only) it is host memory in the packed form below. */
+#define NTEDIT_HIP_BASES_HOST 0
+#define NTEDIT_HIP_BASES_DEVICE 1
+#define NTEDIT_HIP_BASES_PACKED 2
+
+/* The packed form of a batch: what crosses PCIe when the producer of the batch (a FASTA parser touches every byte
+ * anyway) hands it over as 4-bit character codes instead of bytes -- 5 bits per base instead of 8 on a link that is
+ * slower than the screening (3 GB of draft: ~110 ms at 27 GB/s against ~95 ms of screening).  Layout, for n bytes:
+ *   codes   ceil(n / 32) * 16 bytes: two codes per byte, even position in the low nibble; 0..13 = the accepted bases
+ *           A C G T R Y S W K M B D H V (either case), 15 = anything else (N, separators, ...)
+ *   case    ceil(n / 128) * 16 bytes, right behind the codes: bit i (LSB first) = byte i is a lower-case letter
+ * The device unpacks it into the byte batch every kernel reads (code 15 comes back as 'N' / 'n': to the hot path every
+ * non-accepted byte is the same, ntedit.cpp:493-499), so results do not depend on the form.  Bytes that are NOT the
+ * same to it -- U / u and the handful of other bytes whose ntHash seed is not zero (nte_common.h, is_exotic) -- cannot
+ * be packed: ntedit_hip_pack_bases() then returns 1 and the caller hands the batch over as bytes.
+ * `bases` stays the batch for ntedit_hip_write_outputs() either way (the renderer copies draft bytes).
+ * threads: 0 = the ntedit_hip_set_host_threads() setting.  Returns 0, 1 (not packable) or NTEDIT_E_ARG. */
+uint64_t ntedit_hip_packed_size(uint64_t n);
+int ntedit_hip_pack_bases(const char* bases, uint64_t n, void* packed, unsigned threads);
 
 /* Page-locked host memory for batches (optional): a batch handed over from such a buffer crosses PCIe
  * asynchronously, in pieces, while the pieces already in HBM are being screened.  Any other host memory

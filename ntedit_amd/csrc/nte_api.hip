@@ -90,6 +90,7 @@ struct ntedit_hip_ctx
 	float last_ms = 0.f;
 	hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 	hipEvent_t ev_assess[2] = { nullptr, nullptr };
+	DevBuf packed; // a batch as it crossed PCIe in the packed form (NTEDIT_HIP_BASES_PACKED), before k_unpack
 	DevBuf runmap; // the absent bitmap minus the positions that cannot do anything (k_assess)
 	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters, deferred;
 	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps, ws_win;
@@ -733,11 +734,30 @@ run_screen_binned(ntedit_hip_ctx* c, const u8* d_seq, u64 n, const Filter& f, u6
 	return 0;
 }
 
+// bytes [o, o + len) of a batch that arrives in the packed form (o a multiple of 128, or the whole batch): its codes and
+// case bits cross PCIe, k_unpack turns them into bytes of c->seq -- all on `stream`
+int
+copy_packed_piece(ntedit_hip_ctx* c, const char* packed, u64 n, u64 o, u64 len, hipStream_t stream)
+{
+	const u64 codes_bytes = (n + 31) / 32 * 16;
+	const u64 end = o + len;
+	const u64 c0 = o / 2, c1 = end == n ? codes_bytes : end / 2;
+	const u64 s0 = o / 8, s1 = end == n ? (n + 127) / 128 * 16 : end / 8;
+	HIP_TRY(c, hipMemcpyAsync((char*)c->packed.p + c0, packed + c0, c1 - c0, hipMemcpyHostToDevice, stream));
+	HIP_TRY(c, hipMemcpyAsync((char*)c->packed.p + codes_bytes + s0, packed + codes_bytes + s0, s1 - s0, hipMemcpyHostToDevice, stream));
+	const u64 g0 = o / 16, g1 = (end + 15) / 16; // (c->seq has 64 bytes of slack behind the batch)
+	const u64 blocks = (g1 - g0 + 255) / 256;
+	hipLaunchKernelGGL(k_unpack, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, (const u8*)c->packed.p,
+	                   (const u8*)c->packed.p + codes_bytes, (u8*)c->seq.p, g0, g1 - g0);
+	HIP_TRY(c, hipGetLastError());
+	return 0;
+}
+
 // copies (or adopts) the batch into HBM; returns the device pointer
 int
 stage_bases(ntedit_hip_ctx* c, const char* bases, u64 n, int on_device, const u8** out, bool copy = true)
 {
-	if (on_device) {
+	if (on_device == NTEDIT_HIP_BASES_DEVICE) {
 		if ((uintptr_t)bases & 15) {
 			return fail(c, NTEDIT_E_ARG, "device `bases` must be 16-byte aligned");
 		}
@@ -748,7 +768,15 @@ stage_bases(ntedit_hip_ctx* c, const char* bases, u64 n, int on_device, const u8
 	if (rc) {
 		return rc;
 	}
-	if (copy) {
+	if (on_device == NTEDIT_HIP_BASES_PACKED) {
+		// the packed form: codes + case bits to HBM, k_unpack writes the byte batch (in pieces: copy_packed_piece)
+		if ((rc = ensure(c, c->packed, (size_t)((n + 31) / 32 * 16 + (n + 127) / 128 * 16)))) {
+			return rc;
+		}
+		if (copy && (rc = copy_packed_piece(c, bases, n, 0, n, c->stream))) {
+			return rc;
+		}
+	} else if (copy) {
 		HIP_TRY(c, hipMemcpyAsync(c->seq.p, bases, n, hipMemcpyHostToDevice, c->stream));
 	}
 	*out = (const u8*)c->seq.p;
@@ -847,7 +875,7 @@ ntedit_hip_destroy(ntedit_hip_ctx* c)
 	}
 	DevBuf* bufs[] = { &c->seq,      &c->bitmap,   &c->block_counts, &c->block_offsets, &c->events,
 		               &c->first_chunk, &c->arena, &c->counters, &c->deferred,     &c->ws_nodes,      &c->ws_ov_pos,
-		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->runmap, &c->bin_records[0], &c->bin_records[1], &c->bin_fill[0], &c->bin_fill[1], &c->bin_ctl[0], &c->bin_ctl[1], &c->bin_ovf[0], &c->bin_ovf[1], &c->bin_lost, &c->ev_cover, &c->ev_before, &c->ev_flags, &c->ev_list, &c->ev_bmax,       &c->offs,          &c->lens };
+		               &c->ws_ov_chr, &c->ws_prev, &c->ws_lps, &c->ws_win, &c->runmap, &c->packed, &c->bin_records[0], &c->bin_records[1], &c->bin_fill[0], &c->bin_fill[1], &c->bin_ctl[0], &c->bin_ctl[1], &c->bin_ovf[0], &c->bin_ovf[1], &c->bin_lost, &c->ev_cover, &c->ev_before, &c->ev_flags, &c->ev_list, &c->ev_bmax,       &c->offs,          &c->lens };
 	for (DevBuf* b : bufs) {
 		release(*b);
 	}
@@ -1138,6 +1166,9 @@ ntedit_hip_filter_insert(ntedit_hip_ctx* c, int slot, const char* bases, uint64_
 		HIP_TRY(c, hipMemcpy(c->d_tab, tab, sizeof tab, hipMemcpyHostToDevice));
 		c->tab_k = df.k;
 	}
+	if (on_device != NTEDIT_HIP_BASES_HOST && on_device != NTEDIT_HIP_BASES_DEVICE) {
+		return fail(c, NTEDIT_E_ARG, "filter_insert: bases must be host or device bytes");
+	}
 	const u8* d_seq = nullptr;
 	rc = stage_bases(c, bases, n, on_device, &d_seq);
 	if (rc == 0) {
@@ -1234,6 +1265,9 @@ ntedit_hip_screen(ntedit_hip_ctx* c, const char* bases, uint64_t n, int on_devic
 	int rc = refresh_params(c);
 	if (rc) {
 		return rc;
+	}
+	if (on_device != NTEDIT_HIP_BASES_HOST && on_device != NTEDIT_HIP_BASES_DEVICE) {
+		return fail(c, NTEDIT_E_ARG, "screen: bases must be host or device bytes");
 	}
 	const u64 n_words = (n + 63) / 64;
 	const u8* d_seq = nullptr;
@@ -1382,7 +1416,7 @@ PolishRun::plan()
 	if (c->tune.h2d_piece != ~0ULL) { // tests / tuning: bytes per piece (0 = one copy up front)
 		h2d_piece = c->tune.h2d_piece / SCREEN_TILE * SCREEN_TILE;
 	}
-	h2d_overlap = !on_device && h2d_piece > 0 && n > 2 * h2d_piece;
+	h2d_overlap = on_device != NTEDIT_HIP_BASES_DEVICE && h2d_piece > 0 && n > 2 * h2d_piece;
 	if ((rc = stage_bases(c, bases, n, on_device, &d_seq, !h2d_overlap))) {
 		return rc;
 	}
@@ -1524,6 +1558,12 @@ PolishRun::launch_screening(int attempt)
 	hipStream_t s_copy = sB;
 	auto copy_piece = [&](u64 j) -> hipError_t {
 		const u64 o = j * h2d_piece, len = o + h2d_piece < n ? h2d_piece : n - o;
+		if (on_device == NTEDIT_HIP_BASES_PACKED) {
+			if (copy_packed_piece(c, bases, n, o, len, s_copy)) {
+				return hipErrorUnknown;
+			}
+			return hipEventRecord(c->h2d_ev[j], s_copy);
+		}
 		hipError_t e = hipMemcpyAsync((char*)c->seq.p + o, bases + o, len, hipMemcpyHostToDevice, s_copy);
 		return e != hipSuccess ? e : hipEventRecord(c->h2d_ev[j], s_copy);
 	};
@@ -2297,7 +2337,7 @@ ntedit_hip_polish_batch(
     int on_device,
     ntedit_hip_result** out)
 {
-	if (!c || !out || (n && !bases) || (n_contigs && (!offsets || !lens))) {
+	if (!c || !out || (n && !bases) || (n_contigs && (!offsets || !lens)) || on_device < 0 || on_device > NTEDIT_HIP_BASES_PACKED) {
 		return fail(c, NTEDIT_E_ARG, "polish_batch: bad argument");
 	}
 	*out = nullptr;

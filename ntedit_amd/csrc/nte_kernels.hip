@@ -85,6 +85,36 @@ stage_tile(const u8* __restrict__ seq, u64 n, u64 tile_base, u32 tile_len, u32 k
 }
 
 
+// ------------------------------------------------------------------ k_unpack
+// A batch that crossed PCIe in the packed form (include/ntedit_hip.h: 4-bit codes + a case bit per base) back into
+// the byte batch every kernel reads: 16 bases per thread -- 8 bytes of codes, 2 bytes of case bits in, one 16-byte
+// store out.  5 bytes of HBM traffic per 16 bases on top of the 16 written: ~2 ms per 3 Gbp.
+__global__ __launch_bounds__(256) void
+k_unpack(const u8* __restrict__ codes, const u8* __restrict__ cases, u8* __restrict__ out, u64 first16, u64 n16)
+{
+	const u64 LET_LO = 0x5753595254474341ULL; // "ACGTRYSW" (codes 0..7), little endian
+	const u64 LET_HI = 0x4E4E564844424D4BULL; // "KMBDHVNN" (codes 8..15)
+	for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n16; i += (u64)gridDim.x * 256) {
+		const u64 g = first16 + i; // group of 16 bases
+		const u64 c = *reinterpret_cast<const u64*>(codes + g * 8);
+		const u32 cs = *reinterpret_cast<const unsigned short*>(cases + g * 2);
+		u64 w[2];
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			u64 v = 0;
+#pragma unroll
+			for (int b = 0; b < 8; b++) {
+				const u32 code = (u32)(c >> (4 * (8 * h + b))) & 15u;
+				u32 ch = (u32)(((code & 8u) ? LET_HI : LET_LO) >> (8 * (code & 7u))) & 0xFFu;
+				ch |= ((cs >> (8 * h + b)) & 1u) << 5; // lower case
+				v |= (u64)ch << (8 * b);
+			}
+			w[h] = v;
+		}
+		*reinterpret_cast<ulonglong2*>(out + g * 16) = make_ulonglong2(w[0], w[1]);
+	}
+}
+
 template<int H, bool POW2, bool INSERT>
 __global__ __launch_bounds__(SCREEN_TPB) void
 k_screen(

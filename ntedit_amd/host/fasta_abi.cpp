@@ -8,8 +8,12 @@
 #include "fasta.h"
 #include "fasta_map.h"
 
+#include "../csrc/nte_common.h"
+
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -118,6 +122,94 @@ ntedit_hip_fasta_load(const char* path, uint64_t min_len, unsigned threads, nted
 	}
 	*out = f;
 	return 0;
+}
+
+// ---- the packed form of a batch (include/ntedit_hip.h)
+uint64_t
+ntedit_hip_packed_size(uint64_t n)
+{
+	return (n + 31) / 32 * 16 + (n + 127) / 128 * 16;
+}
+
+int
+ntedit_hip_pack_bases(const char* bases, uint64_t n, void* packed, unsigned threads)
+{
+	if ((n && !bases) || !packed) {
+		return NTEDIT_E_ARG;
+	}
+	// per byte: low nibble = code, bit 4 = lower-case letter, bit 7 = the packed form cannot carry this byte
+	static uint8_t lut[256];
+	static std::once_flag once;
+	std::call_once(once, []() {
+		for (int c = 0; c < 256; c++) {
+			const uint8_t code = nte::char_code((uint8_t)c);
+			lut[c] = (uint8_t)(code | ((c >= 'a' && c <= 'z') ? 0x10 : 0) | (nte::is_exotic((uint8_t)c) ? 0x80 : 0));
+		}
+	});
+	uint8_t* codes = (uint8_t*)packed;
+	uint8_t* cases = codes + (n + 31) / 32 * 16;
+	memset(cases, 0, (size_t)((n + 127) / 128 * 16));
+	if (n & 1) {
+		codes[n / 2] = 0xF0; // (the odd tail's high nibble; the padding behind it is never read as bases)
+	}
+	if (threads == 0) {
+		threads = std::thread::hardware_concurrency();
+		threads = threads > 16 ? 16 : (threads < 1 ? 1 : threads);
+	}
+	const uint64_t unit = 1u << 20; // (a multiple of 128: no two threads share a byte of either section)
+	const uint64_t n_units = (n + unit - 1) / unit;
+	if (threads > n_units) {
+		threads = (unsigned)(n_units ? n_units : 1);
+	}
+	std::atomic<uint64_t> next(0);
+	std::atomic<int> bad(0);
+	auto work = [&]() {
+		for (;;) {
+			const uint64_t u = next.fetch_add(1);
+			if (u >= n_units || bad.load(std::memory_order_relaxed)) {
+				return;
+			}
+			const uint64_t a = u * unit, b = a + unit < n ? a + unit : n;
+			const uint8_t* src = (const uint8_t*)bases;
+			uint8_t flags = 0;
+			uint64_t i = a;
+			for (; i + 8 <= b; i += 8) {
+				uint8_t t[8];
+				for (int q = 0; q < 8; q++) {
+					t[q] = lut[src[i + q]];
+				}
+				flags |= t[0] | t[1] | t[2] | t[3] | t[4] | t[5] | t[6] | t[7];
+				codes[i / 2] = (uint8_t)((t[0] & 15) | (t[1] << 4));
+				codes[i / 2 + 1] = (uint8_t)((t[2] & 15) | (t[3] << 4));
+				codes[i / 2 + 2] = (uint8_t)((t[4] & 15) | (t[5] << 4));
+				codes[i / 2 + 3] = (uint8_t)((t[6] & 15) | (t[7] << 4));
+				cases[i / 8] = (uint8_t)(((t[0] >> 4) & 1) | ((t[1] >> 3) & 2) | ((t[2] >> 2) & 4) | ((t[3] >> 1) & 8) | (t[4] & 16) |
+				                         ((t[5] << 1) & 32) | ((t[6] << 2) & 64) | ((t[7] << 3) & 128));
+			}
+			for (; i < b; i++) { // (the batch's last bytes)
+				const uint8_t t = lut[src[i]];
+				flags |= t;
+				if (i & 1) {
+					codes[i / 2] = (uint8_t)((codes[i / 2] & 15) | (t << 4));
+				} else {
+					codes[i / 2] = (uint8_t)((codes[i / 2] & 0xF0) | (t & 15));
+				}
+				cases[i / 8] |= (uint8_t)(((t >> 4) & 1) << (i & 7));
+			}
+			if (flags & 0x80) {
+				bad.store(1);
+			}
+		}
+	};
+	std::vector<std::thread> pool;
+	for (unsigned t = 1; t < threads; t++) {
+		pool.emplace_back(work);
+	}
+	work();
+	for (std::thread& t : pool) {
+		t.join();
+	}
+	return bad.load() ? 1 : 0;
 }
 
 uint64_t

@@ -253,11 +253,35 @@ class Polisher:
                                                 ctypes.c_void_p(bitmap_ptr)), "screen")
         return self._lib.ntedit_hip_last_kernel_ms(self._h)
 
-    def polish_batch(self, blob, offsets, lens, device_ptr=None, n=None):
+    def pack_bases(self, blob, out=None, threads=0):
+        """The packed form of a host batch (4-bit codes + case bits, include/ntedit_hip.h), or None when the batch holds a
+        byte that form cannot carry.  out: a uint8 buffer of packed_size(len(blob)) bytes (e.g. page-locked)."""
+        n = len(blob)
+        size = int(self._lib.ntedit_hip_packed_size(n))
+        if out is None:
+            out = np.empty(size, dtype=np.uint8)
+        assert out.nbytes >= size
+        keep, ptr = Result._blob_ptr(blob)
+        rc = self._lib.ntedit_hip_pack_bases(ptr, n, out.ctypes.data_as(ctypes.c_void_p), threads)
+        del keep
+        if rc < 0:
+            raise NtEditHipError("pack_bases failed (%d)" % rc)
+        return None if rc else out
+
+    def packed_size(self, n):
+        return int(self._lib.ntedit_hip_packed_size(n))
+
+    def polish_batch(self, blob, offsets, lens, device_ptr=None, n=None, packed=None):
+        """packed: the batch's packed form (pack_bases); it crosses PCIe instead of `blob`, whose length is still the batch's"""
         res = ctypes.c_void_p()
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
-        if device_ptr is not None:
+        if packed is not None:
+            rc = self._lib.ntedit_hip_polish_batch(self._h, packed.ctypes.data_as(ctypes.c_void_p), len(blob),
+                                                   offsets.ctypes.data_as(ctypes.c_void_p),
+                                                   lens.ctypes.data_as(ctypes.c_void_p), len(lens), 2,
+                                                   ctypes.byref(res))
+        elif device_ptr is not None:
             rc = self._lib.ntedit_hip_polish_batch(self._h, ctypes.c_void_p(device_ptr), n,
                                                    offsets.ctypes.data_as(ctypes.c_void_p),
                                                    lens.ctypes.data_as(ctypes.c_void_p), len(lens), 1,
@@ -292,7 +316,9 @@ class Polisher:
         if annot_path:
             if self._lib.ntedit_hip_annot_load(annot_path.encode(), ctypes.byref(annot)):
                 raise NtEditHipError("cannot read %s" % annot_path)
-        res = self.polish_batch(blob, offs, lens)
+        # (send_packed: the batch crosses PCIe as 4-bit codes + case bits when it can; the renderer keeps the bytes)
+        packed = self.pack_bases(blob) if getattr(self, "send_packed", False) and len(blob) else None
+        res = self.polish_batch(blob, offs, lens, packed=packed)
         res.write(blob, offs, lens, names, fa, tsv, append=True, vcf_path=vcf, snv=bool(self.params.snv), annot=annot)
         if annot_path:
             self._lib.ntedit_hip_annot_free(annot)

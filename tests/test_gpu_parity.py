@@ -296,6 +296,32 @@ def test_polish_chunk_pipeline(tmp_path, ci, screen_mode, oracle_build):
         assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / (g + "_edited.fa")), shallow=False)
 
 
+@pytest.mark.parametrize("ci", [0, 2, 3, 5, 9, 17, 31])
+def test_polish_packed_batch(tmp_path, ci, oracle_build):
+    """the batch crosses PCIe in the packed form (4-bit codes + a case bit per base, unpacked on the device) -- whole, and
+    in pieces under the screening: the same bytes come out (N runs, lower case, IUPAC codes; a draft with a byte the
+    form cannot carry is handed over as bytes)"""
+    case_kw, par_kw = H.PARITY_CONFIGS[ci]
+    case = H.make_case(str(tmp_path), 7700 + ci, **case_kw)
+    hp = H.default_params(**par_kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), case["rep"])
+    recs = H.read_fasta(case["draft"])
+    for pieces in (0, 1):
+        pol = _fresh()
+        pol.send_packed = True
+        if pieces:
+            pol.set_tuning("h2d_piece", 16384)
+        try:
+            _load_filters(pol, case)
+            pol.set_params(_hip_params(**par_kw))
+            pol.polish_records(recs, str(tmp_path / "g"))
+        finally:
+            pol.close()
+        for suf in ("_changes.tsv", "_edited.fa"):
+            assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("g" + suf)), shallow=False), (suf, pieces)
+        assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "g_variants.vcf"))
+
+
 @pytest.mark.parametrize("chunked", [0, 1])
 @pytest.mark.parametrize("screen_mode", [1, 2])
 def test_polish_batch_arriving_in_pieces(tmp_path, screen_mode, chunked, oracle_build):

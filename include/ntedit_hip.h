@@ -367,15 +367,20 @@ void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
 
 /* Test and tuning knobs (not part of the reference surface).  NONE of them can change a result: they pick between
  * implementations that are bit-identical by construction (and tested to be), split work differently, or print
- * timings.  Keys: "screen_mode" (overrides params.screen_mode), "bin_chunk" (k-mer starts per record chunk of the
- * partitioned screening), "bin_cap_percent" (record-run capacity in percent of the expectation: forces the overflow
- * list), "bin_fallback" (1: direct kernel from now on, as after a lost overflow), "bin_scatter" (1: the barrier-free
- * partition kernel), "bin_overlap" (partition a record chunk while the previous one is probed), "probe_parts_log2",
- * "records_uncached", "force_xcc" (x + 1: the probe stage behaves as if every wavefront ran on XCD x), "bin_timing",
- * "chunk_bytes" (pipeline chunk size), "h2d_piece" (bytes per host-to-device piece), "h2d_chunks" (a large batch in
- * host memory is polished in this many pipeline chunks, its pieces crossing on a stream of their own), "inline_tries",
- * "screen_lds_pad", "no_rounds", "force_rounds", "machine_pieces" (an event round in this many pieces, the sweep launch of
- * piece i next to the thread-per-event launch of piece i + 1; 0 / 1 = one piece), "no_early_copy", "no_lds_ws".
+ * timings.  Keys:
+ *   screening   "screen_mode" (overrides params.screen_mode), "bin_chunk" (k-mer starts per record chunk of the
+ *               partitioned screening), "bin_cap_percent" (record-run capacity in percent of the expectation: forces the
+ *               overflow list), "bin_fallback" (1: direct kernel from now on, as after a lost overflow), "bin_scatter"
+ *               (1: the barrier-free partition kernel, kept as the second implementation the tests compare),
+ *               "force_xcc" (x + 1: the probe stage behaves as if every wavefront ran on XCD x), "bin_timing"
+ *   batches     "chunk_bytes" (pipeline chunk size), "h2d_piece" (bytes per host-to-device piece)
+ *   machine     "inline_tries", "no_rounds", "force_rounds", "no_early_copy", "lanes" (runs of failing positions one
+ *               position per lane: 0 off, 1 in the clean state, 2 also behind substitutions), "defer_run" (hand-over
+ *               threshold of the thread-per-event launch), "assess" (the run map: 0 never, 1 always; default: with -s 1
+ *               and counting filters), "machine_cfg" (0: the general instantiation of the machine kernels)
+ * (The measured-and-rejected variants of round 3 -- record chunks partitioned while the previous one is probed, slices
+ * probed in parts, uncached records, event rounds in pieces, a batch polished in pipeline chunks as it arrives -- are
+ * gone from the library; DESIGN.md 8 keeps their numbers, the history their code.)
  * The library reads two environment variables only: NTEDIT_HIP_DEBUG (diagnostics on stderr) and
  * NTEDIT_HIP_NO_BIND (see ntedit_hip_bind_near_device). */
 int ntedit_hip_set_tuning(ntedit_hip_ctx* ctx, const char* key, uint64_t value);

@@ -337,8 +337,6 @@ struct ProbeArgs
 	u32 force_xcc;   // PROBE_XCC_ANY, or the XCD id every workgroup pretends to run on (tests)
 	u32 counting;    // the filter holds 8-bit counters: a slot is a byte, "absent" = counter < count_lo
 	u32 count_lo;    // max(1, -p) (ntedit.cpp:1806)
-	u32 parts_log2;  // a slice is walked 2^parts_log2 times, each walk probing the records of one part of it: the part
-	                 // (not the whole slice) has to stay in the XCD's L2 next to the record stream; n_slices counts walks
 };
 
 __device__ __forceinline__ u32
@@ -402,7 +400,6 @@ k_bin_probe(ProbeArgs a)
 	const u32 xcd = a.force_xcc == PROBE_XCC_ANY ? xcc_id() : (a.force_xcc & 15u);
 	const u32 capr = (a.cap + PROBE_STEP - 1) / PROBE_STEP * PROBE_STEP; // a run in the counter's coordinates
 	const u32 total = a.n_wg * capr;
-	const u32 part_shift = a.slog - a.parts_log2;
 	const u32 bsh = a.counting ? 0u : 3u; // slots per byte, as a shift
 	u32 sl = NONE32, p = 0; // (thread 0: the draw made ahead)
 	for (u32 it = 0;; it++) {
@@ -426,8 +423,7 @@ k_bin_probe(ProbeArgs a)
 		if (at >= total) {
 			continue;
 		}
-		const u32 rsl = dsl >> a.parts_log2;                 // the slice of the record array
-		const u32 part = dsl & ((1u << a.parts_log2) - 1);  // the part of it this walk probes
+		const u32 rsl = dsl; // the slice of the record array
 		const u8* __restrict__ fs = a.filter + ((u64)rsl << (a.slog - bsh));
 		const u32 w = at / capr;
 		const u32 i0 = at - w * capr;
@@ -468,9 +464,6 @@ k_bin_probe(ProbeArgs a)
 #pragma unroll
 		for (int q = 0; q < PROBE_PER; q++) {
 			const u32 off = (u32)(rec[q] & off_mask);
-			if (rec[q] == WC_EMPTY_REC || (off >> part_shift) != part) {
-				rec[q] = WC_EMPTY_REC; // (padding, or another walk's record)
-			}
 			byte[q] = rec[q] != WC_EMPTY_REC ? fs[off >> bsh] : (u8)0xFF;
 		}
 #pragma unroll
@@ -564,10 +557,11 @@ k_count_starts(
 			ta += s_abs[i];
 		}
 		block_counts[blockIdx.x] = tc;
-		if (ta) {
-			atomicAdd(&counters[0], (unsigned long long)ta);
-		}
+		// (the absent k-mers of the block go behind the counts: 183 k blocks bumping ONE counter took 2 ms per 3 Gbp;
+		// k_scan_counts adds them up)
+		block_counts[gridDim.x + blockIdx.x] = ta;
 	}
+	(void)counters;
 }
 
 // exclusive scan of block_counts (single workgroup); counters[1] = total
@@ -580,13 +574,16 @@ k_scan_counts(
 {
 	__shared__ unsigned long long s_part[1024];
 	__shared__ unsigned long long s_carry;
+	__shared__ unsigned long long s_abs[16];
 	if (threadIdx.x == 0) {
 		s_carry = 0;
 	}
 	__syncthreads();
+	unsigned long long absent = 0; // block_counts[n_blocks + b]: absent k-mers of block b (k_count_starts)
 	for (u64 base = 0; base < n_blocks; base += 1024) {
 		const u64 i = base + threadIdx.x;
 		const unsigned long long v = i < n_blocks ? block_counts[i] : 0;
+		absent += i < n_blocks ? block_counts[n_blocks + i] : 0;
 		s_part[threadIdx.x] = v;
 		__syncthreads();
 		// Hillis-Steele inclusive scan
@@ -610,7 +607,19 @@ k_scan_counts(
 		}
 		__syncthreads();
 	}
+	for (int off = 32; off > 0; off >>= 1) {
+		absent += __shfl_down(absent, off, 64);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		s_abs[threadIdx.x >> 6] = absent;
+	}
+	__syncthreads();
 	if (threadIdx.x == 0) {
+		unsigned long long a = 0;
+		for (int i = 0; i < 16; i++) {
+			a += s_abs[i];
+		}
+		counters[0] += a; // (this chunk's; the counter is zeroed per attempt)
 		counters[1] = s_carry;
 	}
 }
@@ -670,21 +679,33 @@ k_write_starts(
 constexpr u8 EVC_PRIMARY = 0x20, EVC_SKIPPED = 0x40, EVC_RAN = 0x80; // (+ EV_UNFINISHED = 0x10 from the machine)
 constexpr int EVR_TPB = 256;
 
+// appends the values of the lanes with `pred` to list[*count...], in thread order within the workgroup (EVR_TPB threads,
+// every thread of the workgroup calls it): ONE bump of the counter per workgroup
 __device__ __forceinline__ void
 wave_append(u32* list, u32* count, bool pred, u32 value)
 {
+	__shared__ u32 s_n[EVR_TPB / 64];
+	__shared__ u32 s_base;
 	const u64 m = __ballot(pred);
-	if (m) {
-		const u32 lane = __lane_id();
-		const u32 leader = (u32)__ffsll((long long)m) - 1;
-		u32 base = 0;
-		if (lane == leader) {
-			base = atomicAdd(count, (u32)__popcll(m));
+	const u32 lane = __lane_id(), wave = threadIdx.x >> 6;
+	if (lane == 0) {
+		s_n[wave] = (u32)__popcll(m);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		u32 t = 0;
+		for (int i = 0; i < EVR_TPB / 64; i++) {
+			t += s_n[i];
 		}
-		base = __shfl(base, leader, 64);
-		if (pred) {
-			list[base + (u32)__popcll(m & ((1ULL << lane) - 1))] = value;
+		s_base = t ? atomicAdd(count, t) : 0u;
+	}
+	__syncthreads();
+	if (pred) {
+		u32 off = s_base;
+		for (u32 i = 0; i < wave; i++) {
+			off += s_n[i];
 		}
+		list[off + (u32)__popcll(m & ((1ULL << lane) - 1))] = value;
 	}
 }
 

@@ -245,6 +245,9 @@ struct MachineT
 	// presence of the next k-mers while the window still overlaps an edit (see build_lookahead)
 	u32 la_mask, la_n, la_i;
 	bool la_off;
+	// what the support count of an applied substitution already knows about the k-mers behind it (see process_missing):
+	// valid for a look-ahead built with the head cursor at la_known_pos
+	u32 la_known, la_known_vals, la_known_pos;
 	bool changed_seq; // the last failing position applied an edit (else the sequence, and the look-ahead, still stand)
 	bool la_win;      // the character window is still the one the look-ahead was hashed from (the stride needs it)
 #if defined(NTE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -745,6 +748,7 @@ struct MachineT
 	{
 		u32 present, total;
 		bool aborted, gave_up;
+		u64 pmask; // bit n: the n-th k-mer of the subset (in walk order; the first 64) is there
 	};
 
 	// SPLIT: the first group holds only as many k-mers as it takes to know that need_present is out of reach
@@ -757,6 +761,7 @@ struct MachineT
 		SubsetResult r;
 		r.present = 0;
 		r.total = 0;
+		r.pmask = 0;
 		r.aborted = false;
 		r.gave_up = false;
 		u32 kk = kk0;
@@ -803,7 +808,13 @@ struct MachineT
 			if (nb == 0) {
 				break;
 			}
-			r.present += popc32(present_group<G>(b, nb, solid_check));
+			{
+				const u32 pm = present_group<G>(b, nb, solid_check);
+				r.present += popc32(pm);
+				if (r.total < 64) {
+					r.pmask |= (u64)pm << r.total;
+				}
+			}
 			r.total += nb;
 			cap = G;
 			if (kk > last) {
@@ -1928,6 +1939,8 @@ struct MachineT
 	{
 		la_n = la_i = 0;
 		la_mask = 0;
+		const bool use_known = la_known_pos == h_seq_i; // (see process_missing; good for this one look-ahead only)
+		la_known_pos = NONE32;
 		if (!fill_window()) {
 			la_off = true; // near the contig end: probe position by position
 			return;
@@ -1959,6 +1972,9 @@ struct MachineT
 		}
 		HashState ts = hs;
 		u32 n = 0;
+		// (k-mers the last substitution's support count has probed already: see process_missing)
+		const u32 known = use_known ? la_known : 0u;
+		const u32 known_vals = use_known ? la_known_vals : 0u;
 		while (n < L) {
 			u64 b[8];
 			u32 nb = 0;
@@ -1973,7 +1989,8 @@ struct MachineT
 					nb = (u32)u + 1;
 				}
 			}
-			la_mask |= probe_group_range<8>(e.bloom, b, nb, p.min_thr > 1 ? p.min_thr : 1, 255) << n;
+			const u32 skip = (known >> n) & 0xFFu;
+			la_mask |= (probe_group_range<8>(e.bloom, b, nb, p.min_thr > 1 ? p.min_thr : 1, 255, ~skip) | ((known_vals >> n) & skip & ((1u << nb) - 1))) << n;
 			n += nb;
 		}
 		la_n = L;
@@ -2176,6 +2193,8 @@ struct MachineT
 
 		u8 cand[4];
 		u32 n_cand = candidate_bases(draft_char, snv(), cand);
+		u64 cand_mask[4] = { 0, 0, 0, 0 }; // presence of the subset k-mers behind every candidate (SubsetResult::pmask)
+		u32 cand_total[4] = { 0, 0, 0, 0 };
 		Node t_nd = nget(t_node);
 		for (u32 ci = 0; ci < n_cand; ci++) {
 			u8 sub_base = cand[ci];
@@ -2210,6 +2229,8 @@ struct MachineT
 					    return true;
 				    });
 				check_present = r.gave_up ? 0 : r.present;
+				cand_mask[ci & 3] = r.pmask;
+				cand_total[ci & 3] = r.gave_up ? 0 : r.total;
 			} else
 			for (u32 k = 0; k < p.k && th < e.len && tt < e.len; k++) {
 				if (roll(th, tt, thn, ttn, char_out, char_in)) {
@@ -2275,6 +2296,24 @@ struct MachineT
 		}
 		NTE_PROF_SUB(2); // candidates (substitutions + indel sweeps)
 		changed_seq = b.edit_type != 0;
+		la_known = la_known_vals = 0;
+		la_known_pos = NONE32;
+		if (b.edit_type == 1 && win_ok && mode() != 2 && !secbf() && !counting() && !snv() && t_nd.type == 0 && linear()) {
+			// The k-mers behind a substitution are probed again as the cursors roll over them (the look-ahead).  The
+			// support count of the winning candidate has probed every jump-th of them already -- with a plain filter and
+			// no secondary one "there and solid" is the main loop's "present": the next look-ahead takes those over.
+			for (u32 ci = 0; ci < n_cand; ci++) {
+				if (cand[ci] == b.sub_base && cand_total[ci] && cand_total[ci] <= 64) {
+					// look-ahead index i (built one roll from here) = the k-mer i + 1 rolls behind this one = walk index i,
+					// in the subset when i % jump == 0
+					for (u32 i = 0, n = 0; i < 32 && n < cand_total[ci]; i += p.jump, n++) {
+						la_known |= 1u << i;
+						la_known_vals |= (u32)((cand_mask[ci] >> n) & 1) << i;
+					}
+					la_known_pos = h_seq_i + 1;
+				}
+			}
+		}
 		make_edit(draft_char, b);
 		NTE_PROF_SUB(3);
 	}
@@ -2970,6 +3009,8 @@ struct MachineT
 		la_mask = la_n = la_i = 0;
 		la_off = false;
 		la_win = false;
+		la_known = la_known_vals = 0;
+		la_known_pos = NONE32;
 		changed_seq = false;
 		first_chunk = cur_chunk = NONE32;
 		fill = 0;

@@ -148,8 +148,8 @@ make_dev_params(
 	}
 	d.event_budget = budget;
 	d.lanes = 2;     // runs of failing positions one position per lane (nte_machine.h, run_lanes)
-	d.defer_run = 2; // ... from the third failing position of a clean run on
-	d.inline_tries = 8; // (3 Gbp bench, sweep launch at 64 lanes per event: 4 / 8 / 16 tries -> machine 47.8 / 47.2 / 47.6 ms)
+	d.defer_run = 8; // ... when the clean run goes on for at least 8 more positions (3 Gbp: 2 / 4 / 8 / 16 -> machine 32.4 / 32.7 / 32.0 / 32.7 ms)
+	d.inline_tries = 16; // (3 Gbp bench: 4 / 8 / 16 tries -> machine 32.8 / 32.4 / 31.9 ms; round 3, before the lanes: 47.8 / 47.2 / 47.6)
 	for (uint32_t i = 0; i < nte::MAX_HASHES; i++) {
 		d.mul[i] = (uint64_t)i ^ ((uint64_t)k * nte::MULTISEED);
 	}

@@ -33,16 +33,16 @@ def _load_filters(pol, case):
         pol.load_filter_file(case["rep"], 1)
 
 
-def _fresh(pol_cls=None, force_rounds=True, pieces=0):
+def _fresh(pol_cls=None, force_rounds=True, general=False):
     """a polisher for the small cases of this file: the event rounds (which the library only uses from ~2 M events of a
     batch on) are forced, so that their selection / verification kernels see every configuration"""
     import ntedit_amd
     pol = ntedit_amd.Polisher(0)
     if force_rounds:
         pol.set_tuning("force_rounds", 1)
-    if pieces:
-        # a round in pieces: the sweeps of piece i run next to pass 1 of piece i + 1 (two streams)
-        pol.set_tuning("machine_pieces", pieces)
+    if general:
+        # the general instantiation of the machine kernels instead of the one specialised for the configuration
+        pol.set_tuning("machine_cfg", 0)
     return pol
 
 
@@ -52,8 +52,9 @@ def test_polish_matches_oracle(tmp_path, ci, oracle_build):
     case = H.make_case(str(tmp_path), 1000 + ci, **case_kw)
     hp = H.default_params(**par_kw)
     H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), case["rep"])
-    # (both ways of running the events: in rounds, all at once; every other round run in 3 pieces)
-    pol = _fresh(force_rounds=ci % 2 == 0, pieces=3 if ci % 4 == 0 else 0)
+    # (both ways of running the events: in rounds, all at once; every third configuration on the general machine kernels
+    # although a specialised instantiation would do)
+    pol = _fresh(force_rounds=ci % 2 == 0, general=ci % 3 == 0)
     try:
         _load_filters(pol, case)
         pol.set_params(_hip_params(**par_kw))

@@ -133,9 +133,18 @@ def main():
                         cmd += ["--tune", "bin_scatter=1"]
                 if rng.random() < 0.5:
                     cmd += ["--tune", "force_rounds=1"]  # (the event rounds, which small batches do not use by themselves)
-                    if rng.random() < 0.6:
-                        # a round in pieces: sweeps of piece i next to pass 1 of piece i + 1
-                        cmd += ["--tune", "machine_pieces=%d" % int(rng.choice([2, 3, 5]))]
+                # the machine's launch scheme: runs of failing positions one per lane or not, hand-over threshold of the first
+                # pass, the run map, the general kernels instead of the specialised ones, packed batches
+                if rng.random() < 0.4:
+                    cmd += ["--tune", "lanes=%d" % int(rng.choice([0, 1, 2]))]
+                if rng.random() < 0.4:
+                    cmd += ["--tune", "defer_run=%d" % int(rng.choice([0, 1, 3, 20]))]
+                if rng.random() < 0.4:
+                    cmd += ["--tune", "assess=%d" % int(rng.choice([0, 1]))]
+                if rng.random() < 0.3:
+                    cmd += ["--tune", "machine_cfg=0"]
+                if rng.random() < 0.4:
+                    cmd += ["--pack"]
                 if "start_grid" in par_kw:
                     cmd += ["--start-grid", str(par_kw["start_grid"])]
                 if "event_budget" in par_kw:

@@ -39,9 +39,10 @@ PY
 done
 rm -rf $OUT/trace
 # per-launch HBM traffic of our kernels (fabric read requests x 64 B + WRITE_SIZE KiB x 1024), for bench.py's roofline.traffic
-python - "$OUT/pmc_summary.txt" "$OUT/roofline_traffic.json" "$TAG" <<'PY'
+python - "$OUT/pmc_summary.txt" "$OUT/roofline_traffic.json" "$TAG" "$OUT/trace_bench.json" <<'PY'
 import json, re, sys
 txt, out, tag = open(sys.argv[1]).read(), sys.argv[2], sys.argv[3]
+line = json.loads(open(sys.argv[4]).readline())  # (the bench line of the traced run: workload and build of the kernels)
 agg = {}
 for line in txt.splitlines():
     m = re.match(r"(.*?) dispatches=(\d+) (.*)", line)
@@ -61,6 +62,7 @@ for name, d in agg.items():
                      "write_bytes_per_launch": d["WRITE_SIZE"] * 1024 / n,
                      "tcc_hit_rate": d["TCC_HIT_sum"] / max(1.0, d["TCC_HIT_sum"] + d["TCC_MISS_sum"]) if "TCC_HIT_sum" in d else None}
 json.dump({"source": "profiles/%s_pmc_summary.txt (rocprofv3 --pmc, one counter group per run; reads = TCC_EA0_RDREQ x 64 B, writes = WRITE_SIZE KiB x 1024)" % tag,
+           "workload_bytes": line["config"]["workload_bytes"], "build_id": line.get("build_id"),
            "kernels": res}, open(out, "w"), indent=1)
 PY
 ls -la $OUT

@@ -19,19 +19,26 @@
 namespace nte {
 
 constexpr int ASSESS_TPB = 256;
-constexpr int ASSESS_MAX_WIN = ASSESS_TPB + 2 * 200 + 10 + 1 + 16; // k <= 200, max_deletions <= 10 (params.cpp)
+constexpr int ASSESS_L = 16;                          // consecutive positions per lane (a quarter of a bitmap word)
+constexpr int ASSESS_TILE = ASSESS_TPB * ASSESS_L;    // positions per workgroup tile
+constexpr int ASSESS_MAX_WIN = ASSESS_TILE + 2 * 200 + 10 + 1 + 32; // k <= 200, max_deletions <= 10 (params.cpp)
 
+// A lane walks ASSESS_L consecutive positions: it seeds the hash of its first k-mer from the window and ROLLS from
+// there on (2 table look-ups per position instead of 2k), keeps count of the accepted codes in front of it (the window
+// of a position has to hold k + win_len_in() of them), and asks Machine::assess_gate() where the absent bitmap has the
+// position.  Four lanes make one word of the run map.
 __global__ __launch_bounds__(ASSESS_TPB) void
 k_assess(AssessArgs a)
 {
 	__shared__ u64 s_tab[TAB_WORDS];
 	__shared__ __attribute__((aligned(16))) u8 s_win[ASSESS_MAX_WIN];
-	__shared__ u32 s_exotic;
 	if (threadIdx.x < TAB_WORDS) {
 		s_tab[threadIdx.x] = a.tabs[threadIdx.x];
 	}
-	const u32 K = a.p.k + a.p.max_deletions + 1; // Machine::win_len_in()
-	const u32 span = ASSESS_TPB + a.p.k + K;     // codes a tile's lanes read
+	const u32 k = a.p.k;
+	const u32 K = k + a.p.max_deletions + 1; // Machine::win_len_in()
+	const u32 need = k + K;                  // accepted codes a position's window holds
+	const u32 span = ASSESS_TILE + need;     // codes a tile's lanes read
 	EventEnv env;
 	env.seq = a.seq;
 	env.batch_end = a.seq + a.n_bytes;
@@ -56,20 +63,23 @@ k_assess(AssessArgs a)
 	env.arena_chunks = 0;
 	env.defer_sweeps = false;
 	env.wave_size = 1;
+	const u32 x0 = threadIdx.x * ASSESS_L;
 	for (u64 tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-		const u64 base = a.pos_begin + tile * ASSESS_TPB; // (a multiple of 64)
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			s_exotic = 0;
+		const u64 base = a.pos_begin + tile * ASSESS_TILE; // (a multiple of 64)
+		__syncthreads(); // (the window of the previous tile is no longer read)
+		// this lane's quarter of a bitmap word
+		const u64 p0 = base + x0;
+		u32 abits = 0;
+		if (p0 < a.pos_end) {
+			abits = (u32)(a.bitmap[p0 >> 6] >> (p0 & 63)) & 0xFFFFu;
+			if (a.pos_end - p0 < ASSESS_L) {
+				abits &= (1u << (a.pos_end - p0)) - 1;
+			}
 		}
-		__syncthreads();
-		// does the tile hold an absent k-mer at all?
-		const bool in_range = base + (threadIdx.x & ~63u) < a.pos_end; // (this wavefront's bitmap word exists)
-		const u64 word = in_range ? a.bitmap[(base >> 6) + (threadIdx.x >> 6)] : 0;
-		const bool mine = base + threadIdx.x < a.pos_end && ((word >> (threadIdx.x & 63)) & 1);
-		if (!__syncthreads_or(mine ? 1 : 0)) {
-			if ((threadIdx.x & 63) == 0 && in_range) {
-				a.runmap[(base >> 6) + (threadIdx.x >> 6)] = 0;
+		if (!__syncthreads_or(abits != 0)) {
+			// nothing absent in the whole tile
+			if ((threadIdx.x & 3) == 0 && p0 < a.pos_end) {
+				a.runmap[p0 >> 6] = 0;
 			}
 			continue;
 		}
@@ -83,28 +93,42 @@ k_assess(AssessArgs a)
 			}
 			s_win[i] = code;
 		}
-		if (exotic) {
-			s_exotic = 1; // (benign race: every writer stores 1)
-		}
-		__syncthreads();
-		bool keep = mine;
-		if (mine && !s_exotic) {
-			// the window of this lane: k + K accepted codes from its offset on, or the bit stays
-			bool clear = true;
-			for (u32 i = 0; i < a.p.k + K; i++) {
-				clear = clear && s_win[threadIdx.x + i] != CODE_BAD;
+		// (a byte the 4-bit codes cannot express anywhere in the tile: every absent position keeps its bit)
+		const bool plain = !__syncthreads_or(exotic ? 1 : 0);
+		u32 keep = abits;
+		if (plain && abits) {
+			MachineT<0> m(env);
+			m.win_ok = true;
+			m.win_off = x0;
+			HashState hs = m.seed_from_window();
+			// accepted codes in a row ending at the far end of the first position's window
+			u32 good = 0;
+			for (u32 i = 0; i < need; i++) {
+				good = s_win[x0 + i] != CODE_BAD ? good + 1 : 0;
 			}
-			if (clear) {
-				MachineT<0> m(env);
-				m.win_off = threadIdx.x;
-				m.win_ok = true;
-				m.hs = m.seed_from_window();
-				keep = m.assess_gate(base + threadIdx.x, a.seq[base + threadIdx.x + a.p.k - 1]);
+			keep = 0;
+			for (u32 j = 0; j < (u32)ASSESS_L; j++) {
+				if ((abits >> j) & 1) {
+					bool kp = true;
+					if (good >= need) {
+						m.win_off = x0 + j;
+						m.hs = hs;
+						kp = m.assess_gate(p0 + j, a.seq[p0 + j + k - 1]);
+					}
+					keep |= kp ? 1u << j : 0u;
+				}
+				// on to the next position
+				hash_roll(hs, s_tab, s_win[x0 + j], s_win[x0 + j + k]);
+				good = s_win[x0 + j + need] != CODE_BAD ? good + 1 : 0;
 			}
+			// (Probing the candidates of a lane's 16 positions together -- 16 gathers per filter level in flight instead of
+			// three or four -- was built and measured: 70 instead of 35 ms per 250 Mbp with -s 1.  The wavefronts in flight
+			// already keep the memory system busy; the unrolled 16-wide bookkeeping only added instructions.)
 		}
-		const u64 out = __ballot(keep);
-		if ((threadIdx.x & 63) == 0 && in_range) {
-			a.runmap[(base >> 6) + (threadIdx.x >> 6)] = out;
+		// four lanes = one word
+		const u32 k1 = (u32)__shfl_down((int)keep, 1, 64), k2 = (u32)__shfl_down((int)keep, 2, 64), k3 = (u32)__shfl_down((int)keep, 3, 64);
+		if ((threadIdx.x & 3) == 0 && p0 < a.pos_end) {
+			a.runmap[p0 >> 6] = (u64)keep | ((u64)k1 << 16) | ((u64)k2 << 32) | ((u64)k3 << 48);
 		}
 	}
 }
@@ -118,7 +142,7 @@ launch_k_assess(unsigned blocks, hipStream_t stream, const AssessArgs& a)
 int
 assess_tile()
 {
-	return ASSESS_TPB;
+	return ASSESS_TILE;
 }
 
 } // namespace nte

@@ -2428,11 +2428,21 @@ struct MachineT
 		return code < 14 ? (u8)"ACGTRYSWKMBDHV"[code] : (u8)'N';
 	}
 
-	// i-th of up to 16 counts packed into two words
+	// i-th of up to LANE_COUNTS counts packed into four words
+	static constexpr u32 LANE_COUNTS = 32;
 	NTE_HD static u32
-	packed_byte(u64 lo, u64 hi, u32 i)
+	packed_byte(const u64 (&w)[4], u32 i)
 	{
-		return (u32)(((i < 8 ? lo : hi) >> (8 * (i & 7))) & 0xFF);
+		const u64 v = i < 16 ? (i < 8 ? w[0] : w[1]) : (i < 24 ? w[2] : w[3]);
+		return (u32)((v >> (8 * (i & 7))) & 0xFF);
+	}
+
+	// The per-lane assessment keeps the counts of the subset k-mers that are there (counting filters, -s 1: their median
+	// decides) in registers: configurations whose subset is larger take the position-by-position paths.
+	NTE_HD bool
+	lane_counts_fit() const
+	{
+		return !(counting() || snv()) || (p.k - 1) / p.jump + 1 <= LANE_COUNTS;
 	}
 
 	// what one lane knows about its position after the phases every lane runs by itself
@@ -2592,7 +2602,7 @@ struct MachineT
 	lane_step2_counts(u8 draft_char, u32& check_missing, u32& check_there, u32& there_median) const
 	{
 		HashState ts = hs;
-		u64 c_lo = 0, c_hi = 0;
+		u64 cw[4] = { 0, 0, 0, 0 }; // (lane_counts_fit(): at most LANE_COUNTS of them)
 		check_missing = 0;
 		check_there = 0;
 		there_median = 0;
@@ -2639,12 +2649,12 @@ struct MachineT
 					if (c == 0) {
 						check_missing++;
 					} else if (acgt && c >= p.min_thr) {
-						if (check_there < 16) {
-							if (check_there < 8) {
-								c_lo |= (u64)c << (8 * check_there);
-							} else {
-								c_hi |= (u64)c << (8 * (check_there - 8));
-							}
+						if (check_there < LANE_COUNTS) {
+							const u64 bits = (u64)c << (8 * (check_there & 7));
+							cw[0] |= check_there < 8 ? bits : 0;
+							cw[1] |= check_there >= 8 && check_there < 16 ? bits : 0;
+							cw[2] |= check_there >= 16 && check_there < 24 ? bits : 0;
+							cw[3] |= check_there >= 24 ? bits : 0;
 						}
 						check_there++;
 					}
@@ -2655,10 +2665,10 @@ struct MachineT
 		const u32 nm = check_there;
 		if (nm) {
 			for (u32 i = 0; i < nm; i++) {
-				const u32 vi = packed_byte(c_lo, c_hi, i);
+				const u32 vi = packed_byte(cw, i);
 				u32 rank = 0;
 				for (u32 j = 0; j < nm; j++) {
-					const u32 vj = packed_byte(c_lo, c_hi, j);
+					const u32 vj = packed_byte(cw, j);
 					rank += (vj < vi || (vj == vi && j < i)) ? 1u : 0u;
 				}
 				if (rank == nm / 2) {
@@ -3096,7 +3106,7 @@ struct MachineT
 				}
 			}
 			bool in_lanes = false;
-			if (LANES && p.lanes && mode() == 0 && !mask() && !p.debug_stop && e.win && (clean || (p.lanes > 1 && linear()))) {
+			if (LANES && p.lanes && mode() == 0 && !mask() && !p.debug_stop && e.win && lane_counts_fit() && (clean || (p.lanes > 1 && linear()))) {
 				// this position and the ones behind it, one per lane
 				u32 walked = 0;
 				in_lanes = run_lanes(walked);
@@ -3144,7 +3154,7 @@ struct MachineT
 					la_off = false;
 				}
 				// (an error nothing fixes fails at every k-mer that covers it: the k-mers ahead are the same ones)
-				if (!LANES && e.defer_sweeps && p.defer_run && !changed_seq && clean && mode() == 0 && !mask() && p.lanes &&
+				if (!LANES && e.defer_sweeps && p.defer_run && !changed_seq && clean && mode() == 0 && !mask() && p.lanes && lane_counts_fit() &&
 				    !(flags & EV_DEFERRED)) {
 					// A clean position that ends without an edit: if the absent run goes on, the following positions
 					// are assessed one per lane by the wavefront-per-event launch instead of one after the other here.

@@ -481,6 +481,12 @@ PARITY_CONFIGS = [
     # a contig of exactly k bases (the 40-base "short" record): never seeded by the reference (ntedit.cpp:527)
     (dict(n=8000, contigs=2, k=40), dict(snv=1, mask=1, min_contig_len=0)),
     (dict(n=20000, contigs=2, k=40, flavor="N"), dict(mask=1, min_contig_len=0)),
+    # counting filter / -s 1 with many subset k-mers: the per-lane assessment keeps at most 32 counts in registers
+    # (k=64, -j 3: 22 of them; k=128: 43 -> the position-by-position paths; found by the GPU fuzz, seeds 91919100436 / ...753)
+    (dict(n=7000, contigs=1, k=64, hashes=2, flavor="cbf", p_sub=2e-3, p_del=3e-4, bfbytes=2048), dict(snv=1, min_threshold=2, max_threshold=4)),
+    (dict(n=7000, contigs=1, k=128, hashes=2, flavor="cbf", p_sub=2e-3, p_del=3e-4, bfbytes=2028), dict(snv=1, jump=1, min_threshold=2, max_threshold=4, missing_threshold=1.5, edit_threshold=25.0, max_insertions=2)),
+    (dict(n=7000, contigs=1, k=128, hashes=1, flavor="N cbf", p_sub=2e-3, p_ins=2e-3, bfbytes=1024), dict(snv=1, min_threshold=3, use_ratio=1, missing_ratio=0.1, edit_ratio=0.1, max_deletions=3)),
+    (dict(n=9000, contigs=2, k=96, flavor="cbf"), dict(min_threshold=2)),
 ]
 
 

@@ -225,6 +225,9 @@ hostsim_polish(
 		if (const char* it = getenv("HOSTSIM_ASSESS")) {
 			assess = atoi(it) != 0;
 		}
+		if ((p.snv || counting != 0) && (p.k - 1) / p.jump + 1 > 32) {
+			assess = false; // (Machine::lane_counts_fit: the per-lane step 2 keeps at most 32 counts)
+		}
 		if (assess) {
 			runmap_store.assign(bitmap.size(), 0);
 			sim_assess((const u8*)bases, n, f, fr, p, tab, bitmap.data(), runmap_store.data());

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: SNV / counting 250 Mbp side lines with tuning variants ("k=v k=v" per variant), after a parity subset
 cd "$GRAFT_REPO_ROOT" || exit 1
-OUT=gpurun_out/r4f; mkdir -p $OUT
+OUT=gpurun_out/sidelines; mkdir -p $OUT
 if [ -z "$SKIP_TESTS" ]; then
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "polish_matches_oracle or screen_bitmap or demo" 2>&1 | grep -v "amdgpu.ids" | tail -5 > $OUT/parity_subset.log; cat $OUT/parity_subset.log
 fi

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: parity subset, then the 3 Gbp step / configs[4]-like / SNV / counting with tuning variants given as arguments ("k=v k=v" per variant)
 cd "$GRAFT_REPO_ROOT" || exit 1
-OUT=gpurun_out/r4c; mkdir -p $OUT
+OUT=gpurun_out/tune; mkdir -p $OUT
 if [ -z "$SKIP_TESTS" ]; then
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "polish_matches_oracle or screen_bitmap or demo" 2>&1 | grep -v "amdgpu.ids" | tail -5 > $OUT/parity_subset.log; cat $OUT/parity_subset.log
 fi

@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -700,8 +701,77 @@ render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigO
 	write_contig(v.names[ci], out_seq, cs, v.want_fa, v.want_tsv, v.want_vcf, v.opt, sg, ci, v.want_edits);
 }
 
+// _changes.tsv and _variants.vcf written by a thread of their own while the calling thread writes _edited.fa: three
+// files, three inode locks -- the FASTA stream (nine tenths of the bytes) no longer waits for the other two.
+class SideWriter
+{
+  public:
+	SideWriter(FILE* tsv, FILE* vcf)
+	  : tsv_(tsv)
+	  , vcf_(vcf)
+	  , th_([this]() { run(); })
+	{}
+	void push(std::string& tsv, std::string& vcf)
+	{
+		Item it;
+		it.tsv.swap(tsv);
+		it.vcf.swap(vcf);
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			q_.push_back(std::move(it));
+		}
+		cv_.notify_one();
+	}
+	void finish()
+	{
+		if (th_.joinable()) {
+			{
+				std::lock_guard<std::mutex> lk(mu_);
+				done_ = true;
+			}
+			cv_.notify_one();
+			th_.join();
+		}
+	}
+	~SideWriter() { finish(); }
+
+  private:
+	struct Item
+	{
+		std::string tsv, vcf;
+	};
+	void run()
+	{
+		for (;;) {
+			Item it;
+			{
+				std::unique_lock<std::mutex> lk(mu_);
+				cv_.wait(lk, [&]() { return done_ || !q_.empty(); });
+				if (q_.empty()) {
+					return;
+				}
+				it = std::move(q_.front());
+				q_.pop_front();
+			}
+			if (tsv_ && !it.tsv.empty()) {
+				fwrite(it.tsv.data(), 1, it.tsv.size(), tsv_);
+			}
+			if (vcf_ && !it.vcf.empty()) {
+				fwrite(it.vcf.data(), 1, it.vcf.size(), vcf_);
+			}
+		}
+	}
+	FILE* tsv_;
+	FILE* vcf_;
+	std::mutex mu_;
+	std::condition_variable cv_;
+	std::deque<Item> q_;
+	bool done_ = false;
+	std::thread th_;
+};
+
 int
-emit_contig(const ContigOut& o, FILE* fa, FILE* tsv, FILE* vcf, RenderStats* st, const RenderOptions& opt, uint32_t first_contig)
+emit_contig(ContigOut& o, FILE* fa, FILE* tsv, FILE* vcf, RenderStats* st, const RenderOptions& opt, uint32_t first_contig, SideWriter* side = nullptr)
 {
 	if (opt.out_sizes && !o.sizes.empty()) {
 		memcpy(opt.out_sizes + (size_t)first_contig * 3, o.sizes.data(), o.sizes.size() * sizeof(uint64_t));
@@ -760,11 +830,16 @@ emit_contig(const ContigOut& o, FILE* fa, FILE* tsv, FILE* vcf, RenderStats* st,
 			}
 		}
 	}
-	if (tsv && !o.tsv.empty()) {
-		fwrite(o.tsv.data(), 1, o.tsv.size(), tsv);
-	}
-	if (vcf && !o.vcf.empty()) {
-		fwrite(o.vcf.data(), 1, o.vcf.size(), vcf);
+	if (side) {
+		// (the small streams go to the side writer, in unit order: the unit's strings are taken out of the slot)
+		side->push(o.tsv, o.vcf);
+	} else {
+		if (tsv && !o.tsv.empty()) {
+			fwrite(o.tsv.data(), 1, o.tsv.size(), tsv);
+		}
+		if (vcf && !o.vcf.empty()) {
+			fwrite(o.vcf.data(), 1, o.vcf.size(), vcf);
+		}
 	}
 	st->events_applied += o.st.events_applied;
 	st->substitutions += o.st.substitutions;
@@ -1061,6 +1136,12 @@ render_batch(
 	int rc = 0;
 	const bool timing = getenv("NTEDIT_HIP_DEBUG") != nullptr;
 	double s_wait = 0, s_emit = 0;
+	// (a FASTA stream next to at least one of the small ones: those get a writer of their own)
+	std::unique_ptr<SideWriter> side;
+	if (fa && (tsv || vcf)) {
+		side.reset(new SideWriter(tsv, vcf));
+	}
+	SideWriter* side_p = side.get();
 	for (uint32_t u = 0; u < n_units; u++) {
 		ContigOut& o = slots[u % W];
 		const auto tw0 = std::chrono::steady_clock::now();
@@ -1073,7 +1154,7 @@ render_batch(
 			rc = o.rc;
 			break;
 		}
-		if ((rc = emit_contig(o, fa, tsv, vcf, st, v.opt, unit_begin[u]))) {
+		if ((rc = emit_contig(o, fa, tsv, vcf, st, v.opt, unit_begin[u], side_p))) {
 			break;
 		}
 		if (timing) {
@@ -1094,6 +1175,9 @@ render_batch(
 	cv_free.notify_all();
 	for (std::thread& t : pool) {
 		t.join();
+	}
+	if (side) {
+		side->finish(); // (everything queued is in the streams' buffers before the caller closes them)
 	}
 	if (timing) {
 		fprintf(stderr, "[ntedit_hip] render: %u units on %u threads, writer waited %.3f s for units, wrote for %.3f s\n", n_units, T, s_wait, s_emit);

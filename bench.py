@@ -465,6 +465,9 @@ def shard_batch(job, pol, rank, world, k, torch):
             pieces)
 
 
+LAST_RANK_SECONDS = []  # per rank: its own seconds of the last timed_steps() (the value is the slowest rank's, barrier included)
+
+
 def timed_steps(step, steps, world, dev, torch, dist):
     """K steps bracketed by barrier + synchronize on both sides; returns (max-over-ranks seconds, per-step stats)"""
     torch.cuda.synchronize()
@@ -473,13 +476,19 @@ def timed_steps(step, steps, world, dev, torch, dist):
     t0 = time.perf_counter()
     out = [step() for _ in range(steps)]
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0  # this rank's own time, before it waits for the others
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    LAST_RANK_SECONDS[:] = [own]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([own], dtype=torch.float64, device=dev)
+        every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(every, mine)
+        LAST_RANK_SECONDS[:] = [float(x.item()) for x in every]
     return elapsed, out
 
 
@@ -581,6 +590,7 @@ def main():
     for i in range(args.warmup):
         (warm if i == 0 and not args.screen_only else step)()
     elapsed, stats = timed_steps(step, args.steps, world, dev, torch, dist)
+    rank_ms_per_step = [round(x / args.steps * 1e3, 3) for x in LAST_RANK_SECONDS]
     screen_ms = [ms for _, ms in stats]
     machine_ms = [st.ms_machine for st, _ in stats if st is not None]
     last = stats[-1][0] if stats else None
@@ -660,6 +670,7 @@ def main():
                 "parallelism": "ONE draft sharded over %d rank(s) by bases (LPT over pieces; %d contig(s) cut into "
                                "segments), filter broadcast once over RCCL (untimed)" % (world, n_cut),
                 "shard_bases": shard_bases,
+                "ms_per_step_by_rank": rank_ms_per_step,  # (each rank's own time; ms_per_step is the slowest one's, barriers included)
                 "segment_cuts_rejected": rejected_total,
             },
             "roofline": {

@@ -13,6 +13,7 @@
 
 #include <atomic>
 #include <cctype>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -118,6 +119,8 @@ struct ntedit_hip_ctx
 	DevBuf ev_cover, ev_before, ev_flags, ev_list, ev_bmax; // event rounds
 	u32 cu_count = 256;
 	size_t lds_per_block = 160 * 1024;
+	double alloc_ms = 0.0;            // host time spent in hipFree + hipMalloc of the grow-only buffers (ensure())
+	u32 alloc_calls = 0;
 	std::vector<PinBuf> pin_pool;
 	std::mutex pin_mu;
 };
@@ -174,6 +177,7 @@ ensure(ntedit_hip_ctx* c, DevBuf& b, size_t bytes)
 	if (bytes <= b.cap) {
 		return 0;
 	}
+	const auto t0 = std::chrono::steady_clock::now();
 	if (b.p) {
 		HIP_TRY(c, hipFree(b.p));
 		b.p = nullptr;
@@ -182,6 +186,12 @@ ensure(ntedit_hip_ctx* c, DevBuf& b, size_t bytes)
 	size_t want = bytes + bytes / 8 + 256;
 	HIP_TRY(c, hipMalloc(&b.p, want));
 	b.cap = want;
+	const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	c->alloc_ms += ms;
+	c->alloc_calls++;
+	if (ms > 1.0 && getenv("NTEDIT_HIP_DEBUG")) {
+		fprintf(stderr, "[ntedit_hip] device buffer of %.1f MB: %.2f ms of hipFree + hipMalloc\n", want / 1e6, ms);
+	}
 	return 0;
 }
 

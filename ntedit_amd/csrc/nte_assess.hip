@@ -30,7 +30,7 @@ constexpr int ASSESS_MAX_WIN = ASSESS_TILE + 2 * 200 + 10 + 1 + 32; // k <= 200,
 __global__ __launch_bounds__(ASSESS_TPB) void
 k_assess(AssessArgs a)
 {
-	__shared__ u64 s_tab[TAB_WORDS];
+	__shared__ __attribute__((aligned(16))) u64 s_tab[TAB_WORDS];
 	__shared__ __attribute__((aligned(16))) u8 s_win[ASSESS_MAX_WIN];
 	if (threadIdx.x < TAB_WORDS) {
 		s_tab[threadIdx.x] = a.tabs[threadIdx.x];

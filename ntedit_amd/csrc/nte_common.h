@@ -234,25 +234,49 @@ sroln(u64 x, unsigned d)
 //   R   reverse seed                      (leaves the reverse hash)
 //   RK  reverse seed rotated by k         (enters the reverse hash)
 //   RK1 reverse seed rotated by k-1       (swap of the LAST base, ntedit.cpp:434-452)
+// Interleaved by use: a roll needs {F, RK} of the base that enters and {FK, R} of the base that leaves, so each pair
+// sits in 16 consecutive bytes -- two 16-byte LDS reads per roll instead of four 8-byte ones.
 enum
 {
-	TAB_F = 0,
-	TAB_FK = 16,
-	TAB_R = 32,
-	TAB_RK = 48,
+	TAB_IN = 0,   // [2c] = F, [2c + 1] = RK
+	TAB_OUT = 32, // [2c] = FK, [2c + 1] = R
 	TAB_RK1 = 64,
 	TAB_WORDS = 80
 };
+
+NTE_HD u64
+tab_f(const u64* tab, u8 c)
+{
+	return tab[TAB_IN + 2 * c];
+}
+
+NTE_HD u64
+tab_rk(const u64* tab, u8 c)
+{
+	return tab[TAB_IN + 2 * c + 1];
+}
+
+NTE_HD u64
+tab_fk(const u64* tab, u8 c)
+{
+	return tab[TAB_OUT + 2 * c];
+}
+
+NTE_HD u64
+tab_r(const u64* tab, u8 c)
+{
+	return tab[TAB_OUT + 2 * c + 1];
+}
 
 inline void
 build_seed_tables(unsigned k, u64* tab)
 {
 	for (u8 c = 0; c < 16; c++) {
 		u64 f = seed_fwd_of_code(c), r = seed_rev_of_code(c);
-		tab[TAB_F + c] = f;
-		tab[TAB_FK + c] = sroln(f, k);
-		tab[TAB_R + c] = r;
-		tab[TAB_RK + c] = sroln(r, k);
+		tab[TAB_IN + 2 * c] = f;
+		tab[TAB_IN + 2 * c + 1] = sroln(r, k);
+		tab[TAB_OUT + 2 * c] = sroln(f, k);
+		tab[TAB_OUT + 2 * c + 1] = r;
 		tab[TAB_RK1 + c] = sroln(r, k - 1);
 	}
 }
@@ -266,15 +290,15 @@ struct HashState
 NTE_HD void
 hash_roll(HashState& s, const u64* tab, u8 out, u8 in)
 {
-	s.fh = srol1(s.fh) ^ tab[TAB_F + in] ^ tab[TAB_FK + out];
-	s.rh = sror1(s.rh ^ tab[TAB_RK + in] ^ tab[TAB_R + out]);
+	s.fh = srol1(s.fh) ^ tab_f(tab, in) ^ tab_fk(tab, out);
+	s.rh = sror1(s.rh ^ tab_rk(tab, in) ^ tab_r(tab, out));
 }
 
 // replace the last base of the current k-mer
 NTE_HD void
 hash_changelast(HashState& s, const u64* tab, u8 out, u8 in)
 {
-	s.fh ^= tab[TAB_F + out] ^ tab[TAB_F + in];
+	s.fh ^= tab_f(tab, out) ^ tab_f(tab, in);
 	s.rh ^= tab[TAB_RK1 + out] ^ tab[TAB_RK1 + in];
 }
 

@@ -127,7 +127,7 @@ k_screen(
     u64 n_words,
     u64 first_tile)
 {
-	__shared__ u64 s_tab[TAB_WORDS];
+	__shared__ __attribute__((aligned(16))) u64 s_tab[TAB_WORDS];
 	__shared__ u8 s_lut[256];
 	__shared__ __attribute__((aligned(16))) u8 s_codes[SCREEN_LDS_BYTES];
 	extern __shared__ u8 s_occupancy_pad[]; // launch-time LDS pad: leaves CU room for k_machine

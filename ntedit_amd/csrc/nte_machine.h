@@ -997,8 +997,8 @@ struct MachineT
 			if (char_code(c) != CODE_BAD) {
 				u32 n = 1;
 				u8 code = char_code(c);
-				u64 fh = e.tab[TAB_F + code];
-				u64 rh = e.tab[TAB_R + code];
+				u64 fh = tab_f(e.tab, code);
+				u64 rh = tab_r(e.tab, code);
 				u32 temp_h_node = temp_t_node;
 				u32 j = i;
 				increment(j, temp_t_node);
@@ -1010,8 +1010,8 @@ struct MachineT
 						i = j;
 						break;
 					}
-					fh = srol1(fh) ^ e.tab[TAB_F + code];
-					rh ^= sroln(e.tab[TAB_R + code], n);
+					fh = srol1(fh) ^ tab_f(e.tab, code);
+					rh ^= sroln(tab_r(e.tab, code), n);
 					n++;
 					if (n == p.k) {
 						break;
@@ -2856,10 +2856,10 @@ struct MachineT
 		s.fh = 0;
 		s.rh = 0;
 		for (u32 i = 0; i < p.k; i++) {
-			s.fh = srol1(s.fh) ^ e.tab[TAB_F + win_o(i)];
+			s.fh = srol1(s.fh) ^ tab_f(e.tab, win_o(i));
 		}
 		for (u32 i = p.k; i > 0; i--) {
-			s.rh = srol1(s.rh) ^ e.tab[TAB_R + win_o(i - 1)];
+			s.rh = srol1(s.rh) ^ tab_r(e.tab, win_o(i - 1));
 		}
 		return s;
 	}
@@ -3040,11 +3040,11 @@ struct MachineT
 		hs.rh = 0;
 		for (u32 i = 0; i < p.k; i++) {
 			u8 code = char_code(e.seq[start + i]);
-			hs.fh = srol1(hs.fh) ^ e.tab[TAB_F + code];
+			hs.fh = srol1(hs.fh) ^ tab_f(e.tab, code);
 		}
 		for (u32 i = p.k; i > 0; i--) {
 			u8 code = char_code(e.seq[start + i - 1]);
-			hs.rh = srol1(hs.rh) ^ e.tab[TAB_R + code];
+			hs.rh = srol1(hs.rh) ^ tab_r(e.tab, code);
 		}
 		u8 char_in = e.seq[t_seq_i];
 		u8 char_out = 0;

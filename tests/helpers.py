@@ -568,3 +568,51 @@ def load_edits_dump(path):
     o = 8 + n * dt.itemsize
     npool = int(np.frombuffer(raw[o:o + 8], dtype="<u8")[0])
     return recs, raw[o + 8:o + 8 + npool]
+
+
+# ---- the reference's demo fixture (demo/ecoli_ntedit_k25_changes.tsv), row by row ------------------------------------------
+# With the proxy filter (k-mers of the genome reconstructed from draft + changes.tsv, 2^28 bytes, h = 3) 4,986 of the
+# reference's 4,997 rows come out byte for byte.  The other 11 are listed here, one by one, with what differs -- the real
+# filter was built from READS, so it lacks k-mers the proxy has (lower support) and holds k-mers of read errors / variants
+# the proxy lacks (alternate bases, higher support); at two loci that changes WHICH of two equivalent edits is found
+# first (the edited genome is the same base for base, test_oracle_demo.py checks all of it).
+DEMO_ROWS_IDENTICAL = 4986
+# same position, same original base, same edit; only the support / alternate columns differ: (position, ref tail, our tail)
+DEMO_ROWS_SUPPORT_ONLY = [
+    ("225886", "A", "G", ["9", "T", "9"], ["9"]),
+    ("275229", "T", "C", ["6"], ["9"]),
+    ("984601", "C", "T", ["9", "G", "3"], ["9"]),
+    ("1159420", "G", "A", ["5"], ["4"]),
+    ("1784783", "C", "-CATT", ["3"], ["8"]),
+    ("2917590", "T", "A", ["9", "C", "4"], ["9"]),
+    ("3385647", "C", "G", ["9", "T", "9"], ["9"]),
+]
+# another, equivalent edit at the same locus (reference rows -> our rows)
+DEMO_ROWS_EQUIVALENT = [
+    ([("1411220", "C", "G", "3"), ("1411223", "C", "+CAC", "8")], [("1411219", "A", "+GCA", "8")]),
+    ([("3085097", "A", "T", "3"), ("3085098", "T", "-T", "8")], [("3085096", "A", "-A", "8")]),
+]
+
+
+def check_demo_rows(ref_lines, got_lines):
+    """Every one of the reference's 4,997 demo rows is accounted for: identical, or one of the 11 listed above with
+    exactly the listed difference.  Anything else -- one more differing row, one listed row changing -- fails."""
+    assert got_lines[0] == ref_lines[0]  # header line, byte for byte
+    ref, got = ref_lines[1:], got_lines[1:]
+    assert len(ref) == 4997
+    rs, gs = set(ref), set(got)
+    assert len(rs) == len(ref) and len(gs) == len(got)
+    assert len(rs & gs) == DEMO_ROWS_IDENTICAL, len(rs & gs)
+    name = ref[0].split("\t")[0]
+    want_ref, want_got = set(), set()
+    for pos, orig, new, rtail, gtail in DEMO_ROWS_SUPPORT_ONLY:
+        want_ref.add("\t".join([name, pos, orig, new] + rtail))
+        want_got.add("\t".join([name, pos, orig, new] + gtail))
+    for rrows, grows in DEMO_ROWS_EQUIVALENT:
+        want_ref.update("\t".join((name,) + r) for r in rrows)
+        want_got.update("\t".join((name,) + g) for g in grows)
+    assert rs - gs == want_ref, sorted(rs - gs)
+    assert gs - rs == want_got, sorted(gs - rs)
+    # the rows both sides have come in the same order
+    common = rs & gs
+    assert [r for r in ref if r in common] == [g for g in got if g in common]

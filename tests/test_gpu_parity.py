@@ -122,14 +122,14 @@ def test_filter_build_matches_oracle(tmp_path, polisher, oracle_build):
 
 def test_demo_ecoli(tmp_path, oracle_build):
     """configs[1]: E. coli demo draft, proxy filter resident in HBM, vs the oracle and vs the
-    reference's committed changes.tsv (soft pin, >= 99% of rows)."""
+    reference's committed changes.tsv (every one of its 4,997 rows accounted for: helpers.check_demo_rows)."""
     import subprocess, sys
     demo = os.path.join(H.GOLDEN, "demo")
     draft = os.path.join(demo, "ecoliWithMismatches001Indels0001.fa.gz")
     ref_tsv = os.path.join(demo, "ecoli_ntedit_k25_changes.tsv")
     subprocess.run([sys.executable, os.path.join(H.GOLDEN, "recon_demo.py"), draft, ref_tsv,
                     str(tmp_path / "truth.fa")], check=True)
-    H.mkbf([str(tmp_path / "truth.fa")], str(tmp_path / "p.bf"), k=25, hashes=3, nbytes=1 << 27)
+    H.mkbf([str(tmp_path / "truth.fa")], str(tmp_path / "p.bf"), k=25, hashes=3, nbytes=1 << 28)
     hp = H.default_params(max_insertions=4, max_deletions=5)
     H.run_oracle(draft, str(tmp_path / "p.bf"), hp, str(tmp_path / "o"))
     pol = _fresh()
@@ -141,10 +141,7 @@ def test_demo_ecoli(tmp_path, oracle_build):
         pol.close()
     assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "g_changes.tsv"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / "g_edited.fa"), shallow=False)
-    ref_rows = set(open(ref_tsv).read().splitlines()[1:])
-    got_rows = set(open(str(tmp_path / "g_changes.tsv")).read().splitlines()[1:])
-    assert len(ref_rows & got_rows) >= 0.99 * len(ref_rows)
-    assert open(ref_tsv).readline() == open(str(tmp_path / "g_changes.tsv")).readline()
+    H.check_demo_rows(open(ref_tsv).read().splitlines(), open(str(tmp_path / "g_changes.tsv")).read().splitlines())
     assert st.bases > 4_600_000
 
 

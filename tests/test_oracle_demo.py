@@ -3,8 +3,11 @@ test (demo/runme.sh:8-10) holds: demo/ecoli_ntedit_k25_changes.tsv.
 
 The reads that built the reference's Bloom filter are not available, so a proxy
 filter is built from the genome reconstructed from draft + changes.tsv
-(tests/golden/recon_demo.py).  With it the oracle reproduces >= 99% of the
-4,997 expected rows byte-for-byte and the complete expected edited genome."""
+(tests/golden/recon_demo.py).  With it the oracle reproduces 4,986 of the
+4,997 expected rows byte-for-byte and the complete expected edited genome; the
+other 11 rows are accounted for one by one (helpers.check_demo_rows): same
+position and edit with another support / alternate column (7 rows), or another
+edit of the same locus that yields the same genome (2 + 2 rows -> 1 + 1)."""
 import os
 import subprocess
 import sys
@@ -26,9 +29,7 @@ def test_oracle_reproduces_reference_demo(tmp_path, oracle_build):
     H.run_oracle(DRAFT, str(tmp_path / "p.bf"), hp, str(tmp_path / "o"))
     ref = open(REF_TSV).read().splitlines()
     got = open(str(tmp_path / "o_changes.tsv")).read().splitlines()
-    assert got[0] == ref[0]  # header line, byte for byte
-    same = len(set(ref[1:]) & set(got[1:]))
-    assert same >= 0.99 * (len(ref) - 1), same
+    H.check_demo_rows(ref, got)
     # the edited genome is reproduced completely
     want_seq = open(truth).read().split("\n")[1]
     got_fa = open(str(tmp_path / "o_edited.fa")).read().split("\n")

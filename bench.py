@@ -64,6 +64,8 @@ def parse():
                     help="N=1 side line: a counting filter of --filter-bytes 8-bit counters (synthetic contents), -p 2")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="ntedit_hip_set_tuning knob (repeatable; none of them changes a result)")
+    ap.add_argument("--no-reserve", action="store_true",
+                    help="skip ntedit_hip_reserve in the set-up: the first step then pays the context's buffer allocations")
     ap.add_argument("--shared-filter", action="store_true",
                     help="use the multi-GPU filter path (torch-owned filter tensor + broadcast) even with 1 rank")
     return ap.parse_args()
@@ -559,6 +561,12 @@ def main():
         my_bases, n_cut = job.n_bases, 0
     my_bytes = int(my_batch.numel())
     torch.cuda.synchronize()
+    # start-up, untimed like the filter load: this rank's buffers + one internal warm-up batch (ntedit_hip_reserve)
+    t_reserve = time.perf_counter()
+    if not args.no_reserve:
+        nres = max(my_bytes, int(job.n_bytes)) if (world > 1 and not args.no_weak) else my_bytes
+        pol.reserve(nres, len(job.lens) + 64, on_device=1)
+    t_reserve = time.perf_counter() - t_reserve
     t_setup = time.perf_counter() - t_setup
 
     launches = [1]
@@ -696,6 +704,7 @@ def main():
                 },
             },
             "setup_s": round(t_setup, 1),
+            "reserve_s": round(t_reserve, 3),
         }
         if weak is not None:
             out["weak"] = weak

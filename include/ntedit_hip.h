@@ -160,6 +160,16 @@ void ntedit_hip_host_free(void* p);
  * node, or -1 when nothing was done (unknown topology, single node, NTEDIT_HIP_NO_BIND set). */
 int ntedit_hip_bind_near_device(int device);
 
+/* Start-up costs out of the first batch (optional; the reference's counterpart is what main() does before its
+ * "reading/processing" stamp, ntedit.cpp:2589: loading the filters).  Call after the filter(s) and parameters are set:
+ * sizes every grow-only device and page-locked buffer for batches of up to max_batch_bytes bytes / max_contigs contigs
+ * (events_hint = expected event starts per batch, 0 = one per 400 bases; on_device = how the batches will arrive,
+ * NTEDIT_HIP_BASES_*), and runs one small internal batch through the current configuration so that kernel code,
+ * kernel attributes and scratch memory are in place.  Fresh device memory maps at ~40 GB/s (the 84 GB of screening
+ * records of a 3 Gbp batch: two seconds); without this call the first ntedit_hip_polish_batch pays that, with it the
+ * first call costs what a warm one does.  Never changes a result; may be called again when the configuration changes. */
+int ntedit_hip_reserve(ntedit_hip_ctx* ctx, uint64_t max_batch_bytes, uint32_t max_contigs, uint64_t events_hint, int on_device);
+
 /* step 1 only (ntedit.cpp:1798-1807): bit i of bitmap (ceil(n/64) words,
  * host memory, or device memory when on_device) is set iff the k-mer starting
  * at byte i consists of accepted bases only and is NOT in the primary filter. */

@@ -309,6 +309,11 @@ struct BinArgs
 // 1 = being claimed, s + 2 = slice s), [32 + s] records of slice s handed out so far.
 // A slice's records: n_wg runs of `cap` records; in the counter's coordinates every run takes capr = cap rounded up to
 // whole steps, so no step crosses runs.
+// Filters beyond 1024 x 4 MiB: the partition kernel has rings for 1024 slices (its LDS), so the slices grow past what
+// an XCD's L2 holds -- 8 MiB at 8 GiB, where half the gathers would miss.  Such a slice is probed in 2^plog PARTS of 4 MiB:
+// the unit the XCDs claim is a (slice, part) pair, the slice's records stream by once per part and every pass probes the
+// records whose slot lies in its part (ctl[] then has one "slice" entry per pair).  Re-reading the records costs less than
+// missing the L2: 8 GiB 88 -> 6x ms, and a 16 GiB filter no longer falls back to the direct kernel (185 ms).
 #ifndef NTE_PROBE_LOAD
 #define NTE_PROBE_LOAD 1 // record loads: 0 = 8 bytes per lane, non-temporal; 1 = 16 bytes, non-temporal; 2 = 16 bytes, plain
 #endif
@@ -337,7 +342,11 @@ struct ProbeArgs
 	u32 force_xcc;   // PROBE_XCC_ANY, or the XCD id every workgroup pretends to run on (tests)
 	u32 counting;    // the filter holds 8-bit counters: a slot is a byte, "absent" = counter < count_lo
 	u32 count_lo;    // max(1, -p) (ntedit.cpp:1806)
+	u32* pf;         // [n_slices << plog] (zeroed): pieces of (slice, part) that have been swept into the L2 ahead of its probes; nullptr = no sweep
+	u64 filter_bytes;
+	u32 plog;        // log2 of the parts a slice is probed in (0: whole slices)
 };
+constexpr u32 PROBE_PF_PARTS = 32; // a slice is swept in this many parts, one per workgroup that comes to it
 
 __device__ __forceinline__ u32
 xcc_id()
@@ -394,21 +403,30 @@ probe_claim(u32* __restrict__ ctl, u32 xcd, u32 n_slices, u32 total, u32& sl, u3
 __global__ __launch_bounds__(PROBE_TPB) void
 k_bin_probe(ProbeArgs a)
 {
-	__shared__ u32 s_draw[2][4]; // {ok, slice, start}, double-buffered: one barrier per draw
+	__shared__ u32 s_draw[2][4]; // {ok, slice, start, part of the slice to sweep}, double-buffered: one barrier per draw
 	const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const u64 off_mask = (1ULL << a.slog) - 1;
 	const u32 xcd = a.force_xcc == PROBE_XCC_ANY ? xcc_id() : (a.force_xcc & 15u);
 	const u32 capr = (a.cap + PROBE_STEP - 1) / PROBE_STEP * PROBE_STEP; // a run in the counter's coordinates
 	const u32 total = a.n_wg * capr;
 	const u32 bsh = a.counting ? 0u : 3u; // slots per byte, as a shift
-	u32 sl = NONE32, p = 0; // (thread 0: the draw made ahead)
+	const u32 n_units = a.n_slices << a.plog; // (slice, part) pairs
+	const u32 part_shift = a.slog - a.plog;
+	u32 sl = NONE32, p = 0; // (thread 0: the draw made ahead; sl counts (slice, part) pairs)
+	u32 swept = NONE32;     // (thread 0: the slice this workgroup took a sweep ticket for last)
 	for (u32 it = 0;; it++) {
 		u32* d = s_draw[it & 1];
 		if (threadIdx.x == 0) {
-			const bool ok = probe_claim(a.ctl, xcd, a.n_slices, total, sl, p);
+			const bool ok = probe_claim(a.ctl, xcd, n_units, total, sl, p);
 			d[0] = ok ? 1u : 0u;
 			d[1] = sl;
 			d[2] = p;
+			d[3] = NONE32;
+			if (ok && a.pf && sl != swept) {
+				// first draw of this workgroup from a new slice: take one part of it to sweep (below)
+				swept = sl;
+				d[3] = atomicAdd(&a.pf[sl], 1u);
+			}
 			if (ok) {
 				// draw the stretch after this one now: its round trip hides behind the probes
 				p = atomicAdd(&a.ctl[CTL_WORK + sl], PROBE_DRAW);
@@ -419,11 +437,33 @@ k_bin_probe(ProbeArgs a)
 			return;
 		}
 		const u32 dsl = d[1];
+		if (d[3] < PROBE_PF_PARTS) {
+			// A slice starts cold: its 2-4 MiB come in through the misses of the first probes, a 128-byte line per random
+			// gather at HBM latency, while every wavefront of the XCD waits.  The first workgroups that come to a slice
+			// therefore sweep one part of it each with coalesced 16-byte loads (plain loads: they stay in the L2) before
+			// they probe; the sum of the parts is the slice, in flight all at once.
+			const u64 unit_bytes = 1ULL << (part_shift - bsh);
+			const u64 part_bytes = unit_bytes / PROBE_PF_PARTS;
+			u64 lo = ((u64)dsl << (part_shift - bsh)) + (u64)d[3] * part_bytes;
+			u64 hi = lo + part_bytes < a.filter_bytes ? lo + part_bytes : a.filter_bytes;
+			lo = lo < hi ? lo : hi;
+			const uintptr_t base = reinterpret_cast<uintptr_t>(a.filter);
+			uintptr_t p0 = (base + lo + 15) & ~(uintptr_t)15, p1 = (base + hi) & ~(uintptr_t)15;
+			u32 acc = 0;
+			for (uintptr_t q = p0 + (uintptr_t)threadIdx.x * 16; q < p1; q += (uintptr_t)PROBE_TPB * 16) {
+				const uint4 v = *reinterpret_cast<const uint4*>(q);
+				acc ^= v.x ^ v.y ^ v.z ^ v.w;
+			}
+			if (acc == 0x9E3779B9u && a.n_slices == NONE32) {
+				a.ctl[CTL_NEXT] = acc; // (never true: keeps the loads)
+			}
+		}
 		const u32 at = d[2] + wave * PROBE_STEP;
 		if (at >= total) {
 			continue;
 		}
-		const u32 rsl = dsl; // the slice of the record array
+		const u32 rsl = dsl >> a.plog; // the slice of the record array
+		const u32 part = dsl & ((1u << a.plog) - 1u);
 		const u8* __restrict__ fs = a.filter + ((u64)rsl << (a.slog - bsh));
 		const u32 w = at / capr;
 		const u32 i0 = at - w * capr;
@@ -464,7 +504,8 @@ k_bin_probe(ProbeArgs a)
 #pragma unroll
 		for (int q = 0; q < PROBE_PER; q++) {
 			const u32 off = (u32)(rec[q] & off_mask);
-			byte[q] = rec[q] != WC_EMPTY_REC ? fs[off >> bsh] : (u8)0xFF;
+			// (a record of another part of the slice reads as "present": it is probed in that part's pass)
+			byte[q] = rec[q] != WC_EMPTY_REC && (off >> part_shift) == part ? fs[off >> bsh] : (u8)0xFF;
 		}
 #pragma unroll
 		for (int q = 0; q < PROBE_PER; q++) {
@@ -519,7 +560,8 @@ constexpr int ST_TPB = 256;
 
 // A range of the batch [pos_lo, pos_hi) (one pipeline chunk = whole contigs) is turned into
 // its ordered event list: words [w0, w0 + gridDim*256).
-// counters[0] += absent k-mers ; block_counts[b] = starts in block b
+// block_counts[b] = starts in block b (from `bitmap`: the screening bitmap or the run map), block_counts[gridDim + b] = absent
+// k-mers of block b (always the set bits of the screening bitmap: ntedit_hip_stats::absent_kmers)
 __global__ __launch_bounds__(ST_TPB) void
 k_count_starts(
     const u64* __restrict__ bitmap,
@@ -530,7 +572,7 @@ k_count_starts(
     u64 grid_lo,
     u32 grid,
     u32* __restrict__ block_counts,
-    unsigned long long* __restrict__ counters)
+    const u64* __restrict__ absent_bitmap) // the screening bitmap (= bitmap unless the starts come from the run map)
 {
 	__shared__ u32 s_cnt[ST_TPB / 64];
 	__shared__ u32 s_abs[ST_TPB / 64];
@@ -539,7 +581,7 @@ k_count_starts(
 	if (w < w1) {
 		const u64 rm = range_mask(w, pos_lo, pos_hi);
 		c = __popcll(start_mask(bitmap, w, grid_lo, grid) & rm);
-		a = __popcll(bitmap[w] & rm);
+		a = __popcll(absent_bitmap[w] & rm);
 	}
 	for (int off = 32; off > 0; off >>= 1) {
 		c += __shfl_down(c, off, 64);
@@ -561,7 +603,6 @@ k_count_starts(
 		// k_scan_counts adds them up)
 		block_counts[gridDim.x + blockIdx.x] = ta;
 	}
-	(void)counters;
 }
 
 // exclusive scan of block_counts (single workgroup); counters[1] = total

@@ -326,6 +326,12 @@ class Polisher:
         res.free()
         return st
 
+    def reserve(self, max_batch_bytes, max_contigs=0, events_hint=0, on_device=0):
+        """ntedit_hip_reserve: buffers for batches of up to max_batch_bytes + one internal warm-up batch, so that the
+        first polish_batch of this context costs what a warm one does (on_device: 0 host, 1 device, 2 packed batches)"""
+        self._check(self._lib.ntedit_hip_reserve(self._h, int(max_batch_bytes), int(max_contigs), int(events_hint),
+                                                 int(on_device)), "reserve")
+
     def set_tuning(self, key, value):
         """Test / tuning knobs (include/ntedit_hip.h: none of them can change a result)."""
         self._check(self._lib.ntedit_hip_set_tuning(self._h, key.encode(), int(value)), "set_tuning")

@@ -166,6 +166,14 @@ def test_binned_screen_matches_oracle(tmp_path, ci, oracle_build):
         got = pol.screen(blob)
         pol.set_tuning("bin_chunk", 0)
         one_chunk = pol.screen(blob)
+        pol.set_tuning("probe_parts_log2", 1 + ci % 3)  # slices probed in 2 / 4 / 8 parts (filters beyond 4 GiB)
+        in_parts = pol.screen(blob)
+        pol.set_tuning("probe_sweep", 0)                # ... and without the sweep that brings a slice into the L2
+        in_parts_cold = pol.screen(blob)
+        pol.set_tuning("probe_parts_log2", 0)
+        unswept = pol.screen(blob)
+        pol.set_tuning("probe_parts_log2", 0xFFFFFFFF)
+        pol.set_tuning("probe_sweep", 1)
         pol.set_tuning("bin_scatter", 1)  # (the barrier-free partition kernel)
         free_one = pol.screen(blob)
         pol.set_tuning("bin_chunk", 3 * 16384)
@@ -177,6 +185,9 @@ def test_binned_screen_matches_oracle(tmp_path, ci, oracle_build):
     assert np.array_equal(direct, want)
     assert np.array_equal(got, want)
     assert np.array_equal(one_chunk, want)
+    assert np.array_equal(in_parts, want)
+    assert np.array_equal(in_parts_cold, want)
+    assert np.array_equal(unswept, want)
     assert np.array_equal(free_one, want)
     assert np.array_equal(free_chunks, want)
 
@@ -776,3 +787,54 @@ def test_cli_mapped_reader_equals_streaming(tmp_path, oracle_build):
         assert r.returncode == 0, r.stderr
         for suf in ("_changes.tsv", "_edited.fa"):
             assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / (tag + suf)), shallow=False), (tag, suf)
+
+
+def test_reserve_first_call_is_warm(tmp_path, oracle_build):
+    """ntedit_hip_reserve: a context's FIRST batch costs what a warm one does (the buffers, page-locked result memory,
+    kernel code and scratch are in place), its result is the one an unreserved context computes, and the screening's
+    event window holds no allocation time even without it (round 4's 184 / 553 ms screening outliers were a fresh 7 GB
+    record buffer being mapped inside that window: DESIGN.md 8)."""
+    import time
+    import ntedit_amd
+    from ntedit_amd.synth import SyntheticJob
+
+    def run(pol, job):
+        t0 = time.perf_counter()
+        res = pol.polish_batch(None, job.offsets, job.lens, device_ptr=job.device_ptr, n=job.n_bytes)
+        st = res.stats()
+        res.free()
+        wall = (time.perf_counter() - t0) * 1e3
+        return wall, st
+
+    def key(st):
+        return (st.absent_kmers, st.events, st.events_deferred)
+
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.set_params(ntedit_amd.default_params())
+        job = SyntheticJob(pol, 128e6, k=25, hash_num=3, filter_bytes=1 << 30, contig_len=100_000, n_runs=False)
+        cold_wall, cold = run(pol, job)
+        assert cold.screen_binned
+        warm = min((run(pol, job) for _ in range(3)), key=lambda x: x[0])
+        bits = pol.filter_device_ptr(0)
+    finally:
+        pass
+    pol2 = ntedit_amd.Polisher(0)
+    try:
+        pol2.set_filter_device(bits, 1 << 30, 3, 25)
+        pol2.set_params(ntedit_amd.default_params())
+        pol2.reserve(job.n_bytes, len(job.lens), on_device=1)
+        first_wall, first = run(pol2, job)
+        again_wall, again = run(pol2, job)
+    finally:
+        pol2.close()
+        pol.close()
+    print("\n[reserve] 128 Mbp: unreserved first call %.1f ms (screen window %.1f), warm %.1f ms (screen %.1f); reserved first call "
+          "%.1f ms (screen %.1f), second %.1f ms" % (cold_wall, cold.ms_screen, warm[0], warm[1].ms_screen, first_wall,
+                                                      first.ms_screen, again_wall), flush=True)
+    assert key(first) == key(cold) == key(warm[1]) == key(again)
+    # the reserved context's first call: within 25 % (+ 1 ms) of a warm call
+    assert first_wall <= 1.25 * warm[0] + 1.0, (first_wall, warm[0])
+    # a screening of this size must take what it takes -- never a multiple (allocations are outside its window)
+    assert cold.ms_screen <= 3.0 * warm[1].ms_screen, (cold.ms_screen, warm[1].ms_screen)
+    assert first.ms_screen <= 1.5 * warm[1].ms_screen + 0.5

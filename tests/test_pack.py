@@ -61,3 +61,27 @@ def test_pack_bases_refuses_what_it_cannot_carry():
             assert lib.ntedit_hip_pack_bases(ctypes.c_char_p(raw), len(raw), out.ctypes.data_as(ctypes.c_void_p), 3) == 1, (bad, at)
     assert lib.ntedit_hip_pack_bases(ctypes.c_char_p(base), len(base), out.ctypes.data_as(ctypes.c_void_p), 3) == 0
     assert lib.ntedit_hip_pack_bases(None, 5, out.ctypes.data_as(ctypes.c_void_p), 1) < 0
+
+
+def test_pack_bases_every_byte_value_both_forms():
+    """every byte value, in the vector form (32 bases per step) and in the table loop (threads | 1 << 31): the same
+    packed bytes, and the same verdict on what the packed form cannot carry (nte_common.h is_exotic: a byte without
+    a code whose reverse-strand seed slot (c & 7) is not empty)"""
+    lib = _lib.load()
+    accepted = set(b"ACGTRYSWKMBDHVacgtryswkmbdhv")
+    fill = b"ACGTNacgtn\nRYKM" * 9  # 144 bytes: the byte under test lands in a whole vector step and in the tail
+    for c in range(256):
+        exotic = c not in accepted and (c & 7) in (1, 3, 4, 5, 7)
+        for at in (0, 37, 100, 143):
+            raw = fill[:at] + bytes([c]) + fill[at + 1:]
+            n = len(raw)
+            size = lib.ntedit_hip_packed_size(n)
+            outs = []
+            for threads in (1, 1 | (1 << 31)):
+                out = np.zeros(size, dtype=np.uint8)
+                rc = lib.ntedit_hip_pack_bases(ctypes.c_char_p(raw), n, out.ctypes.data_as(ctypes.c_void_p), threads)
+                assert rc == (1 if exotic else 0), (c, at, threads)
+                outs.append(out)
+            if not exotic:
+                assert (outs[0] == outs[1]).all(), (c, at)
+                assert (unpack(outs[0], n) == expected_bytes(raw)).all(), (c, at)

@@ -352,6 +352,11 @@ Gunzip::grow_input_()
 {
 	const size_t off = (size_t)(in_ - inbuf_), have0 = (size_t)(in_end_ - inbuf_);
 	const size_t ns = inbuf_size_ * 2;
+	// FEXTRA is at most 64 KiB by format; a file name or comment that has no end within megabytes is damage (or hostile):
+	// fail instead of pulling the whole file into memory (gzread would skip it byte by byte; nobody names a draft that way)
+	if (ns > ((size_t)16 << 20)) {
+		return fail_("invalid header (a field of several megabytes)");
+	}
 	unsigned char* nb = (unsigned char*)realloc(inbuf_, ns + INPAD);
 	if (!nb) {
 		return fail_("out of memory");

@@ -709,20 +709,32 @@ class SideWriter
 	SideWriter(FILE* tsv, FILE* vcf)
 	  : tsv_(tsv)
 	  , vcf_(vcf)
-	  , th_([this]() { run(); })
 	{}
+	// false: no thread could be started -- the caller writes the small streams itself
+	bool start()
+	{
+		try {
+			th_ = std::thread([this]() { run(); });
+		} catch (...) {
+			return false;
+		}
+		return true;
+	}
 	void push(std::string& tsv, std::string& vcf)
 	{
 		Item it;
 		it.tsv.swap(tsv);
 		it.vcf.swap(vcf);
 		{
-			std::lock_guard<std::mutex> lk(mu_);
+			// (bounded: with -s 1 the VCF strings would pile up if that file were slower than the FASTA stream)
+			std::unique_lock<std::mutex> lk(mu_);
+			cv_room_.wait(lk, [&]() { return q_.size() < MAX_QUEUED; });
 			q_.push_back(std::move(it));
 		}
 		cv_.notify_one();
 	}
-	void finish()
+	// everything queued is in the streams' buffers; != 0: a write failed (disk full, ...)
+	int finish()
 	{
 		if (th_.joinable()) {
 			{
@@ -732,10 +744,12 @@ class SideWriter
 			cv_.notify_one();
 			th_.join();
 		}
+		return failed_.load() ? -5 : 0;
 	}
-	~SideWriter() { finish(); }
+	~SideWriter() { (void)finish(); }
 
   private:
+	static constexpr size_t MAX_QUEUED = 256;
 	struct Item
 	{
 		std::string tsv, vcf;
@@ -753,20 +767,22 @@ class SideWriter
 				it = std::move(q_.front());
 				q_.pop_front();
 			}
-			if (tsv_ && !it.tsv.empty()) {
-				fwrite(it.tsv.data(), 1, it.tsv.size(), tsv_);
+			cv_room_.notify_one();
+			if (tsv_ && !it.tsv.empty() && fwrite(it.tsv.data(), 1, it.tsv.size(), tsv_) != it.tsv.size()) {
+				failed_.store(true);
 			}
-			if (vcf_ && !it.vcf.empty()) {
-				fwrite(it.vcf.data(), 1, it.vcf.size(), vcf_);
+			if (vcf_ && !it.vcf.empty() && fwrite(it.vcf.data(), 1, it.vcf.size(), vcf_) != it.vcf.size()) {
+				failed_.store(true);
 			}
 		}
 	}
 	FILE* tsv_;
 	FILE* vcf_;
 	std::mutex mu_;
-	std::condition_variable cv_;
+	std::condition_variable cv_, cv_room_;
 	std::deque<Item> q_;
 	bool done_ = false;
+	std::atomic<bool> failed_{ false };
 	std::thread th_;
 };
 
@@ -834,11 +850,11 @@ emit_contig(ContigOut& o, FILE* fa, FILE* tsv, FILE* vcf, RenderStats* st, const
 		// (the small streams go to the side writer, in unit order: the unit's strings are taken out of the slot)
 		side->push(o.tsv, o.vcf);
 	} else {
-		if (tsv && !o.tsv.empty()) {
-			fwrite(o.tsv.data(), 1, o.tsv.size(), tsv);
+		if (tsv && !o.tsv.empty() && fwrite(o.tsv.data(), 1, o.tsv.size(), tsv) != o.tsv.size()) {
+			return -5;
 		}
-		if (vcf && !o.vcf.empty()) {
-			fwrite(o.vcf.data(), 1, o.vcf.size(), vcf);
+		if (vcf && !o.vcf.empty() && fwrite(o.vcf.data(), 1, o.vcf.size(), vcf) != o.vcf.size()) {
+			return -5;
 		}
 	}
 	st->events_applied += o.st.events_applied;
@@ -1140,6 +1156,9 @@ render_batch(
 	std::unique_ptr<SideWriter> side;
 	if (fa && (tsv || vcf)) {
 		side.reset(new SideWriter(tsv, vcf));
+		if (!side->start()) {
+			side.reset(); // (no thread to be had: the small streams are written inline)
+		}
 	}
 	SideWriter* side_p = side.get();
 	for (uint32_t u = 0; u < n_units; u++) {
@@ -1177,7 +1196,10 @@ render_batch(
 		t.join();
 	}
 	if (side) {
-		side->finish(); // (everything queued is in the streams' buffers before the caller closes them)
+		const int src = side->finish(); // (everything queued is in the streams' buffers before the caller closes them)
+		if (!rc) {
+			rc = src;
+		}
 	}
 	if (timing) {
 		fprintf(stderr, "[ntedit_hip] render: %u units on %u threads, writer waited %.3f s for units, wrote for %.3f s\n", n_units, T, s_wait, s_emit);

@@ -133,6 +133,11 @@ def test_gunzip_header_fields_and_members(tmp_path):
     with open(p, "wb") as f:
         f.write(long_blob[:len(long_blob) // 2 + 40000][:len(member(c, 4 | 8 | 16, extra=b"\x01" * 60000, name=b"n" * 9000, comment=b"c" * 70000)) + 200000])
     assert gunzip(p, tmp_path, 1 << 20, 2048)[0] == -3  # (the file ends inside the second member's name)
+    # a file name that never ends (no NUL within tens of megabytes): an error, not the whole file pulled into memory
+    with open(p, "wb") as f:
+        f.write(member(c, 8, name=b"z" * 300)[:10] + b"z" * (40 << 20))
+    for in_bytes in (2048, 0):
+        assert gunzip(p, tmp_path, 1 << 20, in_bytes)[0] == -3
     # the second member starts, and the file ends inside its header / its data / its trailer
     full = member(a) + member(c)
     for cut in (len(member(a)) + 2, len(member(a)) + 9, len(full) - 9, len(full) - 8, len(full) - 1):

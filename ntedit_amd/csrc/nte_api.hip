@@ -137,6 +137,7 @@ struct ntedit_hip_result
 	ntedit_hip_stats st;
 	nte_host::RenderStats rst;
 	int snv = 0; // -s of the parameters the batch was polished with
+	u32 part_margin = 0; // k + max deletions + slack of those parameters (RenderOptions::part_margin)
 	// ntedit_hip_result_edits(): built on first use
 	bool edits_built = false;
 	std::vector<ntedit_hip_edit> edits;

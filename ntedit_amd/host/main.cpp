@@ -434,7 +434,7 @@ main(int argc, char** argv)
 	// "reading/processing" stamp, like everything else the reference does before it (ntedit.cpp:2564-2589).  Round 2 had
 	// measured page-locking as a loss because it paid for it inside the timed region, three buffers of 1 GiB.
 	Work pool[3];
-	const unsigned long long batch_cap_bases = batch_given ? batch_bases : (1ull << 29);
+	const unsigned long long batch_cap_bases = batch_given ? batch_bases : (1ull << 30);
 	const size_t pin_bytes = (size_t)(batch_cap_bases < (1ull << 32) ? batch_cap_bases : (1ull << 32)) + (size_t)(64u << 20);
 	std::thread pin_thread([&]() {
 		(void)ntedit_hip_bind_near_device(gpu);
@@ -653,12 +653,13 @@ main(int argc, char** argv)
 	memset(&tot, 0, sizeof tot);
 
 	// Batch sizes.  End to end the writer is the slowest stage (a write() per output byte into the page cache), so the
-	// run takes the writer's time plus what passes before its first byte and after the GPU's last: unless the user
-	// fixes the size, the first batches are small (128 Mbases, doubling) and none exceeds 512 Mbases -- the writer
-	// starts after 30 ms instead of 120 and finishes 80 ms behind the GPU instead of 170.
+	// run takes the writer's time plus what passes before its first byte: unless the user fixes the size, the first
+	// batches are small (128 Mbases, doubling: the writer starts after 30 ms instead of 120) and grow to 1 Gbase -- every
+	// batch costs the writer a start-up of its own (round 5: 3 Gbp in 7 batches of <= 512 Mbases 0.52 s of writer time,
+	// in 3 of 1 Gbase 0.43 s).
 	unsigned long long budget = batch_bases;
 	if (!batch_given) {
-		batch_bases = 1ull << 29;
+		batch_bases = 1ull << 30;
 		budget = 1ull << 27;
 	}
 	// Three stages, one batch each at a time: this thread's reader helper parses the draft

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <ctime>
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -179,12 +180,17 @@ struct ContigOut
 	int rc = 0;
 	bool ready = false;
 	size_t fa_bytes = 0;              // bytes of the unit's FASTA pieces so far
-	std::vector<uint64_t> sizes;      // 3 per contig of the unit: fa / tsv / vcf bytes (RenderOptions::out_sizes)
+	std::vector<uint64_t> sizes;      // 4 per job of the unit: contig, fa / tsv / vcf bytes (RenderOptions::out_sizes)
 	std::vector<ntedit_hip_edit> edits; // RenderOptions::edits
 	std::string edit_pool;
+	// the unit's FASTA pieces copied into one stretch by the render thread (multi-threaded rendering): the writer then
+	// hands the kernel a few megabytes per call instead of a thousand spans of a kilobase
+	char* flat = nullptr;
+	size_t flat_n = 0, flat_cap = 0;
 
 	void reset()
 	{
+		flat_n = 0;
 		fa.clear();
 		text.clear();
 		tsv.clear();
@@ -334,7 +340,7 @@ write_vcf_substitution(std::string& vcf, const std::string& H, const RSub& s, co
 // want_edits: every TSV row is also handed on as an ntedit_hip_edit record (entry index ci).
 void
 write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool want_tsv, bool want_vcf, const RenderOptions& opt,
-             const ntedit_hip_segment* sg, uint32_t ci, bool want_edits)
+             const ntedit_hip_segment* sg, uint32_t ci, bool want_edits, uint32_t part_flags = 0)
 {
 	const std::vector<RNode>& nodes = o.nodes;
 	const std::vector<RSub>& subs = o.subs;
@@ -343,7 +349,7 @@ write_contig(const char* hdr, const char* seq, ContigOut& o, bool want_fa, bool 
 	std::string& vcf = o.vcf;
 	const std::string H(hdr);
 	const uint64_t off = sg ? sg->pos_offset : 0;
-	const uint32_t sflags = sg ? sg->flags : 0;
+	const uint32_t sflags = (sg ? sg->flags : 0) | part_flags; // (part_flags: a part of a contig rendered by itself, SubRange)
 	auto add_edit = [&](uint8_t kind, uint32_t dpos, const char* bases, size_t nb, uint32_t support, uint8_t draft, uint8_t nbase,
 	                    const RSub* alt) {
 		ntedit_hip_edit e;
@@ -544,13 +550,26 @@ struct BatchView
 	RenderOptions opt;
 };
 
+// A part of a contig that is rendered by itself (large contigs: one render thread per contig would leave the others idle
+// behind a chromosome).  The contig is cut in front of events that start where the serial run is certainly clean and
+// untouched: no earlier event's run -- applied or not -- comes within PART_MARGIN bases of the cut (render_batch picks the
+// cuts).  A part = the draft positions [pa, pb) and the events that start in them; positions stay the contig's.
+struct SubRange
+{
+	uint32_t pa, pb; // pb = the contig's length for its last part
+	bool first, last;
+};
+constexpr uint32_t PART_MARGIN_EXTRA = 48; // + k: what an event may touch behind the end of its run (tested base, indel look-ahead)
+
 // events [ev, ev_end) of contig ci -> o
 void
-render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigOut& cs)
+render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigOut& cs, const SubRange* sr = nullptr)
 {
 	cs.begin_contig();
 	const char* seq = v.bases + v.offsets[ci];
 	const uint32_t len = v.lens[ci];
+	const uint32_t pa = sr ? sr->pa : 0;
+	const uint32_t part_flags = sr ? ((sr->first ? 0u : (uint32_t)NTEDIT_SEG_NO_HEADER) | (sr->last ? 0u : (uint32_t)NTEDIT_SEG_NO_NEWLINE)) : 0u;
 	const Item* arena = v.arena;
 	const size_t arena_items = v.arena_items;
 	const ntedit_hip_segment* sg = v.opt.segments ? &v.opt.segments[ci] : nullptr;
@@ -561,8 +580,10 @@ render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigO
 		}
 		return; // (an entry that was superseded by a re-run: no output at all)
 	}
-	RNode root = { 0, 0, len ? len - 1 : 0, 0, 0 };
+	RNode root = { 0, pa, len ? len - 1 : 0, 0, 0 };
 	cs.nodes.push_back(root);
+	// (a part's copy of modified bases: its own positions and a margin in front of them, addressed by contig position)
+	const uint32_t ca = sr ? (pa >= 64 ? pa - 64 : 0) : 0, cb = sr && !sr->last ? sr->pb : len;
 	uint32_t cover = 0;
 	bool any = false;
 	for (; ev < ev_end; ev++) {
@@ -648,10 +669,13 @@ render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigO
 				}
 				case nte::TAG_MOD: {
 					if (cs.seq.empty()) {
-						cs.seq.assign(seq, seq + len);
+						cs.seq.assign(seq + ca, seq + cb);
 					}
-					if (it.w[1] < len) {
-						cs.seq[it.w[1]] = (char)((it.w[0] >> 8) & 0xFF);
+					if (it.w[1] >= ca && it.w[1] < cb) {
+						cs.seq[it.w[1] - ca] = (char)((it.w[0] >> 8) & 0xFF);
+					} else if (sr && it.w[1] < len) {
+						cs.rc = -9; // a cut that an event reaches across: render_batch's margin is meant to rule that out
+						return;
 					}
 					break;
 				}
@@ -676,29 +700,105 @@ render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigO
 		}
 		last.e_pos = len - 1 - halo;
 	}
+	if (sr && !sr->last) {
+		// the part ends where the next one begins: in the open node, behind every applied run
+		RNode& last = cs.nodes.back();
+		if (cover > sr->pb || cs.terminated || last.type != 0 || last.e_pos != len - 1 || last.s_pos > sr->pb) {
+			cs.rc = -9;
+			return;
+		}
+		last.e_pos = sr->pb - 1; // (s_pos == pb: an empty node, zero bytes)
+	}
 	const char* out_seq = seq;
 	if (!cs.seq.empty()) {
 		// the record's pieces will point into the modified copy: park it with the unit
 		cs.seq_keep.emplace_back(std::move(cs.seq));
 		cs.seq.clear();
-		out_seq = cs.seq_keep.back().data();
+		out_seq = cs.seq_keep.back().data() - ca; // (addressed by contig position; only [ca, cb) is ever read)
 	}
 	if (!any) {
-		// untouched contig: header + sequence + newline
+		// untouched contig (or part): header + sequence + newline
 		if (v.want_fa) {
-			if (!sg || !(sg->flags & NTEDIT_SEG_NO_HEADER)) {
+			if ((!sg || !(sg->flags & NTEDIT_SEG_NO_HEADER)) && !(part_flags & NTEDIT_SEG_NO_HEADER)) {
 				cs.fa_char('>');
 				cs.fa_text(v.names[ci], strlen(v.names[ci]));
 				cs.fa_char('\n');
 			}
-			cs.fa_span(seq, len - halo);
-			if (!sg || !(sg->flags & NTEDIT_SEG_NO_NEWLINE)) {
+			const uint32_t end = sr && !sr->last ? sr->pb : len - halo;
+			cs.fa_span(seq + pa, end - pa);
+			if ((!sg || !(sg->flags & NTEDIT_SEG_NO_NEWLINE)) && !(part_flags & NTEDIT_SEG_NO_NEWLINE)) {
 				cs.fa_char('\n');
 			}
 		}
 		return;
 	}
-	write_contig(v.names[ci], out_seq, cs, v.want_fa, v.want_tsv, v.want_vcf, v.opt, sg, ci, v.want_edits);
+	write_contig(v.names[ci], out_seq, cs, v.want_fa, v.want_tsv, v.want_vcf, v.opt, sg, ci, v.want_edits, part_flags);
+}
+
+// Buffers for the flattened FASTA output of the render units, kept across render_batch calls: a fresh 8 MB buffer per
+// slot and call is two thousand page faults each.
+class FlatPool
+{
+  public:
+	char* take(size_t bytes, size_t* cap)
+	{
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			for (size_t i = 0; i < bufs_.size(); i++) {
+				if (bufs_[i].second >= bytes) {
+					char* p = bufs_[i].first;
+					*cap = bufs_[i].second;
+					bufs_[i] = bufs_.back();
+					bufs_.pop_back();
+					return p;
+				}
+			}
+		}
+		const size_t want = bytes + bytes / 4 + (1u << 20);
+		char* p = (char*)malloc(want);
+		*cap = p ? want : 0;
+		return p;
+	}
+	void give(char* p, size_t cap)
+	{
+		if (!p) {
+			return;
+		}
+		std::lock_guard<std::mutex> lk(mu_);
+		if (bufs_.size() < 96) {
+			bufs_.emplace_back(p, cap);
+		} else {
+			free(p);
+		}
+	}
+
+  private:
+	std::mutex mu_;
+	std::vector<std::pair<char*, size_t>> bufs_;
+};
+FlatPool g_flat_pool;
+
+// copies the unit's FASTA pieces into o.flat (render thread); false: no memory -- the writer gathers the pieces itself
+bool
+flatten_fa(ContigOut& o)
+{
+	if (o.fa_bytes > o.flat_cap) {
+		g_flat_pool.give(o.flat, o.flat_cap);
+		o.flat = g_flat_pool.take(o.fa_bytes, &o.flat_cap);
+		if (!o.flat) {
+			o.flat_cap = 0;
+			return false;
+		}
+	}
+	char* d = o.flat;
+	for (const Piece& pc : o.fa) {
+		if (pc.n) {
+			memcpy(d, pc.p ? pc.p : o.text.data() + pc.off, pc.n);
+			d += pc.n;
+		}
+	}
+	o.flat_n = (size_t)(d - o.flat);
+	return true;
 }
 
 // _changes.tsv and _variants.vcf written by a thread of their own while the calling thread writes _edited.fa: three
@@ -789,8 +889,13 @@ class SideWriter
 int
 emit_contig(ContigOut& o, FILE* fa, FILE* tsv, FILE* vcf, RenderStats* st, const RenderOptions& opt, uint32_t first_contig, SideWriter* side = nullptr)
 {
-	if (opt.out_sizes && !o.sizes.empty()) {
-		memcpy(opt.out_sizes + (size_t)first_contig * 3, o.sizes.data(), o.sizes.size() * sizeof(uint64_t));
+	(void)first_contig;
+	for (size_t i = 0; opt.out_sizes && i + 3 < o.sizes.size(); i += 4) {
+		// (contig, fa, tsv, vcf bytes): added up, the parts of a contig that was cut come in several units
+		uint64_t* d = opt.out_sizes + (size_t)o.sizes[i] * 3;
+		d[0] += o.sizes[i + 1];
+		d[1] += o.sizes[i + 2];
+		d[2] += o.sizes[i + 3];
 	}
 	if (opt.edits && !o.edits.empty()) {
 		const size_t base = opt.edit_pool->size();
@@ -801,7 +906,22 @@ emit_contig(ContigOut& o, FILE* fa, FILE* tsv, FILE* vcf, RenderStats* st, const
 			(*opt.edits)[i].bases_off += (uint32_t)base;
 		}
 	}
-	if (fa && !o.fa.empty()) {
+	if (fa && o.flat_n) {
+		// (flattened by its render thread: one stretch, a few megabytes)
+		fflush(fa);
+		const int fd = fileno(fa);
+		size_t done = 0;
+		while (done < o.flat_n) {
+			const ssize_t w = write(fd, o.flat + done, o.flat_n - done);
+			if (w < 0) {
+				if (errno == EINTR) {
+					continue;
+				}
+				return -5;
+			}
+			done += (size_t)w;
+		}
+	} else if (fa && !o.fa.empty()) {
 		// the record is a gather of draft spans: hand them to the kernel as they are instead
 		// of copying everything through the stream's buffer first
 		fflush(fa);
@@ -1031,58 +1151,226 @@ render_batch(
 	v.opt = opt_in ? *opt_in : RenderOptions();
 	v.want_edits = v.opt.edits != nullptr && v.opt.edit_pool != nullptr;
 
-	// events of every contig: [ev_begin[ci], ev_begin[ci + 1])
+	// events of every contig: [ev_begin[ci], ev_begin[ci + 1]) -- ev_begin[ci] = the first event with output whose header
+	// names contig ci or a later one (events without output in front of it stay with the contig before; nobody reads
+	// them).  One header read per event: 4.4 M dependent reads per 3 Gbp when done by one thread in front of everything
+	// else, so the events are cut into ranges that are scanned concurrently; the ranges' contig changes are merged.
 	std::vector<size_t> ev_begin((size_t)n_contigs + 1, 0);
+	struct CutCand
 	{
-		size_t ev = 0;
-		for (uint32_t ci = 0; ci < n_contigs; ci++) {
-			ev_begin[ci] = ev;
-			while (ev < n_events) {
+		size_t ev;       // the event in front of which the contig may be cut
+		uint32_t contig;
+		uint32_t pos;    // its start
+		uint32_t seen;   // highest run end among the range's earlier events of the contig
+	};
+	std::vector<std::vector<CutCand>> cand;
+	std::vector<std::vector<std::pair<uint32_t, uint32_t>>> range_max;
+	std::vector<CutCand> cuts; // accepted, in order
+	{
+		unsigned P = v.opt.threads ? v.opt.threads : std::thread::hardware_concurrency();
+		P = P > 16 ? 16 : (P < 1 ? 1 : P);
+		if (n_events < 65536 && v.opt.unit_bases > 1) {
+			P = 1; // (tests render with units of one base: their few events are scanned in ranges all the same)
+		}
+		if (P > n_events) {
+			P = n_events ? (unsigned)n_events : 1;
+		}
+		struct Change
+		{
+			size_t ev;
+			uint32_t contig;
+		};
+		std::vector<std::vector<Change>> found(P);
+		std::vector<int> bad(P, 0);
+		const bool split = v.opt.part_margin > 0 && !v.opt.segments && v.opt.threads != 1;
+		const uint64_t part_bases = v.opt.unit_bases;
+		range_max.assign(P, std::vector<std::pair<uint32_t, uint32_t>>()); // per range: (contig, highest run end seen in it)
+		cand.assign(P, std::vector<CutCand>());
+		auto scan = [&](unsigned t) {
+			const size_t a = n_events * t / P, b = n_events * (t + 1) / P;
+			uint32_t prev = 0;
+			bool have = false;
+			for (size_t ev = a; ev < b; ev++) {
 				const uint32_t fc = ev_first[ev];
 				if (fc == nte::NONE32) {
-					ev++; // an event without output
-					continue;
+					continue; // an event without output
 				}
 				if ((size_t)fc * nte::CHUNK_ITEMS + 1 >= arena_items) {
-					return -1;
+					bad[t] = -1;
+					return;
 				}
-				const uint32_t c = arena[(size_t)fc * nte::CHUNK_ITEMS + 1].w[0];
-				if (c != ci) {
-					if (c < ci) {
-						return -2; // events must arrive in contig order
+				const Item& hd = arena[(size_t)fc * nte::CHUNK_ITEMS + 1];
+				const uint32_t c = hd.w[0];
+				if (!have || c != prev) {
+					if ((have && c < prev) || c >= n_contigs) {
+						bad[t] = -2; // events must arrive in contig order
+						return;
 					}
-					break;
+					found[t].push_back(Change{ ev, c });
+					prev = c;
+					have = true;
+					if (split) {
+						range_max[t].emplace_back(c, 0u);
+					}
 				}
-				ev++;
+				if (split && lens[c] >= 2 * part_bases) {
+					// a place to cut the contig: an event that starts a part's length behind the last cut, with no
+					// run of THIS range's earlier events of the contig within the margin (earlier ranges: the merge)
+					uint32_t& mx = range_max[t].back().second;
+					const uint32_t start = hd.w[1], run_end = hd.w[2];
+					std::vector<CutCand>& cc = cand[t];
+					const uint64_t last_cut = !cc.empty() && cc.back().contig == c ? cc.back().pos : 0;
+					if (start >= last_cut + part_bases && (uint64_t)mx + v.opt.part_margin <= start && (uint64_t)start + part_bases / 2 <= lens[c] &&
+					    !(hd.w[3] & (nte::EV_UNFINISHED | nte::EV_TERMINAL))) {
+						cc.push_back(CutCand{ ev, c, start, mx });
+					}
+					mx = run_end > mx ? run_end : mx;
+				} else if (split) {
+					uint32_t& mx = range_max[t].back().second;
+					mx = hd.w[2] > mx ? hd.w[2] : mx;
+				}
+			}
+		};
+		if (P == 1) {
+			scan(0);
+		} else {
+			std::vector<std::thread> th;
+			for (unsigned t = 1; t < P; t++) {
+				th.emplace_back(scan, t);
+			}
+			scan(0);
+			for (std::thread& t : th) {
+				t.join();
 			}
 		}
-		ev_begin[n_contigs] = ev;
+		const size_t UNSET = ~(size_t)0;
+		std::fill(ev_begin.begin(), ev_begin.end(), UNSET);
+		uint32_t last = 0;
+		bool any = false;
+		for (unsigned t = 0; t < P; t++) {
+			if (bad[t]) {
+				return bad[t];
+			}
+			for (const Change& ch : found[t]) {
+				if (any && ch.contig < last) {
+					return -2;
+				}
+				if (!any || ch.contig != last) {
+					ev_begin[ch.contig] = ch.ev;
+				}
+				last = ch.contig;
+				any = true;
+			}
+		}
+		ev_begin[n_contigs] = n_events;
+		for (size_t ci = n_contigs; ci-- > 0;) {
+			if (ev_begin[ci] == UNSET) {
+				ev_begin[ci] = ev_begin[ci + 1]; // a contig without events
+			}
+		}
+		// cuts: a candidate stands if the runs of the EARLIER ranges' events of its contig keep the margin as well, and if
+		// it is a part's length behind the cut accepted before it (ranges know only their own)
+		if (split) {
+			uint32_t carry_contig = 0xFFFFFFFFu, carry_max = 0;
+			for (unsigned t = 0; t < P; t++) {
+				size_t ri = 0;
+				uint32_t cur_contig = 0xFFFFFFFFu, before = 0; // run ends of earlier ranges for the contig the range opens with
+				for (const CutCand& cc : cand[t]) {
+					while (ri < range_max[t].size() && range_max[t][ri].first != cc.contig) {
+						ri++;
+					}
+					if (cc.contig != cur_contig) {
+						cur_contig = cc.contig;
+						before = (ri == 0 && carry_contig == cc.contig) ? carry_max : 0;
+					}
+					const uint64_t last_cut = !cuts.empty() && cuts.back().contig == cc.contig ? cuts.back().pos : 0;
+					if ((uint64_t)before + v.opt.part_margin <= cc.pos && cc.pos >= last_cut + part_bases) {
+						cuts.push_back(cc);
+					}
+				}
+				// what this range leaves behind for the next one
+				if (!range_max[t].empty()) {
+					const std::pair<uint32_t, uint32_t>& lastc = range_max[t].back();
+					uint32_t m = lastc.second;
+					if (range_max[t].size() == 1 && carry_contig == lastc.first) {
+						m = m > carry_max ? m : carry_max;
+					}
+					carry_contig = lastc.first;
+					carry_max = m;
+				}
+			}
+		}
 	}
 
-	// work units: runs of consecutive contigs of about a megabase (one hand-over, one gather write and one
-	// set of buffers per unit, not per contig: fragmented assemblies have millions of contigs)
-	std::vector<uint32_t> unit_begin;
+	// work units: runs of consecutive contigs of about a megabase (one hand-over, one write and one set of buffers per
+	// unit, not per contig: fragmented assemblies have millions of contigs) -- or ONE part of a contig that was cut
+	struct Job
+	{
+		uint32_t ci;
+		size_t ev_a, ev_b;
+		SubRange sr;
+		bool whole;
+	};
+	std::vector<Job> jobs;
+	std::vector<uint32_t> unit_begin; // into jobs
 	{
 		uint64_t acc = 0;
 		uint32_t cnt = 0;
+		size_t qi = 0;
 		for (uint32_t ci = 0; ci < n_contigs; ci++) {
-			if (ci == 0 || acc >= v.opt.unit_bases || cnt >= 8192) {
-				unit_begin.push_back(ci);
+			size_t q1 = qi;
+			while (q1 < cuts.size() && cuts[q1].contig == ci) {
+				q1++;
+			}
+			if (q1 > qi) {
+				// parts: [0, cut 0), [cut 0, cut 1), ..., [last cut, len)
+				uint32_t pa = 0;
+				size_t ea = ev_begin[ci];
+				for (size_t q = qi; q <= q1; q++) {
+					Job j;
+					j.ci = ci;
+					j.whole = false;
+					j.ev_a = ea;
+					j.ev_b = q < q1 ? cuts[q].ev : ev_begin[ci + 1];
+					j.sr.pa = pa;
+					j.sr.pb = q < q1 ? cuts[q].pos : lens[ci];
+					j.sr.first = q == qi;
+					j.sr.last = q == q1;
+					unit_begin.push_back((uint32_t)jobs.size());
+					jobs.push_back(j);
+					pa = j.sr.pb;
+					ea = j.ev_b;
+				}
+				qi = q1;
+				acc = v.opt.unit_bases; // (the next contig opens a unit of its own)
+				continue;
+			}
+			if (jobs.empty() || acc >= v.opt.unit_bases || cnt >= 8192) {
+				unit_begin.push_back((uint32_t)jobs.size());
 				acc = 0;
 				cnt = 0;
 			}
+			Job j;
+			j.ci = ci;
+			j.whole = true;
+			j.ev_a = ev_begin[ci];
+			j.ev_b = ev_begin[ci + 1];
+			j.sr = SubRange{ 0, lens[ci], true, true };
+			jobs.push_back(j);
 			acc += lens[ci];
 			cnt++;
 		}
-		unit_begin.push_back(n_contigs);
+		unit_begin.push_back((uint32_t)jobs.size());
 	}
 	const uint32_t n_units = (uint32_t)unit_begin.size() - 1;
 	auto render_unit = [&](uint32_t u, ContigOut& o) {
 		o.reset();
-		for (uint32_t ci = unit_begin[u]; ci < unit_begin[u + 1] && !o.rc; ci++) {
+		for (uint32_t ji = unit_begin[u]; ji < unit_begin[u + 1] && !o.rc; ji++) {
+			const Job& j = jobs[ji];
 			const size_t f0 = o.fa_bytes, t0 = o.tsv.size(), v0 = o.vcf.size();
-			render_contig(v, ci, ev_begin[ci], ev_begin[ci + 1], o);
+			render_contig(v, j.ci, j.ev_a, j.ev_b, o, j.whole ? nullptr : &j.sr);
 			if (v.opt.out_sizes) {
+				o.sizes.push_back(j.ci);
 				o.sizes.push_back(o.fa_bytes - f0);
 				o.sizes.push_back(o.tsv.size() - t0);
 				o.sizes.push_back(o.vcf.size() - v0);
@@ -1138,6 +1426,9 @@ render_batch(
 			}
 			ContigOut& o = slots[u % W];
 			render_unit(u, o);
+			if (fa && !o.rc && o.fa_bytes) {
+				(void)flatten_fa(o);
+			}
 			{
 				std::lock_guard<std::mutex> lk(mu);
 				o.ready = true;
@@ -1195,6 +1486,11 @@ render_batch(
 	for (std::thread& t : pool) {
 		t.join();
 	}
+	for (ContigOut& o : slots) {
+		g_flat_pool.give(o.flat, o.flat_cap);
+		o.flat = nullptr;
+		o.flat_cap = 0;
+	}
 	if (side) {
 		const int src = side->finish(); // (everything queued is in the streams' buffers before the caller closes them)
 		if (!rc) {
@@ -1202,7 +1498,7 @@ render_batch(
 		}
 	}
 	if (timing) {
-		fprintf(stderr, "[ntedit_hip] render: %u units on %u threads, writer waited %.3f s for units, wrote for %.3f s\n", n_units, T, s_wait, s_emit);
+		fprintf(stderr, "[ntedit_hip] render: %u units (%zu contig cuts) on %u threads, writer waited %.3f s for units, wrote for %.3f s\n", n_units, cuts.size(), T, s_wait, s_emit);
 	}
 	return rc;
 }

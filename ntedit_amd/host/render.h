@@ -32,6 +32,9 @@ struct RenderOptions
 	const Annotations* annot = nullptr;
 	unsigned threads = 0;           // work units rendered concurrently (0 = up to 8, 1 = in the calling thread)
 	unsigned unit_bases = 1u << 20; // a work unit = consecutive contigs of about this many bases
+	// > 0: contigs of several units are rendered in parts, cut in front of events that no earlier event's run comes within
+	// this many bases of (k + max deletions + slack: what an event may touch behind the end of its run); 0: whole contigs
+	unsigned part_margin = 0;
 	// multi-GPU sharding: entry i is a segment of a larger contig (nullptr: every entry is a whole contig)
 	const ntedit_hip_segment* segments = nullptr;
 	uint64_t* out_sizes = nullptr;  // 3 per entry: bytes the entry added to the fa / tsv / vcf streams

@@ -435,6 +435,11 @@ hostsim_polish(
 	// tests: one contig per work unit unless told otherwise, so that the few-contig cases still go through
 	// the concurrent renderer
 	ropt.unit_bases = getenv("HOSTSIM_RENDER_UNIT") ? (unsigned)atoi(getenv("HOSTSIM_RENDER_UNIT")) : 1;
+	// contigs rendered in parts wherever a cut is allowed (unit of 1 base: every event that keeps the margin opens a part)
+	// -- the library does this for contigs of several megabases; HOSTSIM_RENDER_PARTS=0 turns it off
+	if (!getenv("HOSTSIM_RENDER_PARTS") || atoi(getenv("HOSTSIM_RENDER_PARTS"))) {
+		ropt.part_margin = k + hp->max_deletions + 48;
+	}
 	ropt.snv = hp->snv != 0;
 	nte_host::Annotations* ann = annot_path ? nte_host::annotations_load(annot_path) : nullptr;
 	ropt.annot = ann;

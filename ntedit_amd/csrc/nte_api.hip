@@ -116,7 +116,6 @@ struct ntedit_hip_ctx
 		u32 force_rounds = 0;     // event rounds whatever the number of events (tests: small inputs)
 		u32 bin_scatter = 0;      // partition kernel: 0 barrier-phased (k_wc_scatter_b), 1 barrier-free (k_wc_scatter)
 		u32 probe_parts_log2 = ~0u; // probe stage: slices probed in 2^x parts (~0: by slice size)
-		u32 probe_sweep = ~0u;    // probe stage: 0 = slices come in through the probes' own misses, else swept in ahead (default)
 	} tune;
 	DevBuf ev_cover, ev_before, ev_flags, ev_list, ev_bmax; // event rounds
 	u32 cu_count = 256;

@@ -38,6 +38,13 @@ constexpr u64 SEED_T = 0x295549f54be24456ULL;
 constexpr u64 MULTISEED = 0x90b45d39fb6da1faULL;
 constexpr unsigned MULTISHIFT = 27;
 constexpr unsigned MAX_HASHES = 8;
+// Bounds of the fixed-size per-lane arrays of the event machine (nte_machine_*.inc), checked where the parameters are
+// folded (host/params.cpp: make_dev_params refuses anything beyond them) and asserted where the arrays are declared:
+constexpr unsigned MAX_INSERTION = 5;  // -i (ntedit.cpp:2485-2488): inserted bases of a candidate
+constexpr unsigned MAX_DELETION = 10;  // -d (ntedit.cpp:2489-2493)
+constexpr unsigned MAX_CANDIDATES = 4; // substitution candidates of a position (ntedit.cpp:190-199: at most "ATCG")
+constexpr unsigned INDEL_BYTES = 12;   // u8 ins[] / deleted[] / Best::indel: index base + inserted bases, or the deleted bases
+static_assert(MAX_INSERTION + 1 <= INDEL_BYTES && MAX_DELETION <= INDEL_BYTES, "indel buffers hold the longest candidate");
 
 // Character classes.  Every byte of the draft is mapped to a 4-bit code:
 //   0..3   A C G T (either case)

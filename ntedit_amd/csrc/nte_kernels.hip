@@ -342,11 +342,8 @@ struct ProbeArgs
 	u32 force_xcc;   // PROBE_XCC_ANY, or the XCD id every workgroup pretends to run on (tests)
 	u32 counting;    // the filter holds 8-bit counters: a slot is a byte, "absent" = counter < count_lo
 	u32 count_lo;    // max(1, -p) (ntedit.cpp:1806)
-	u32* pf;         // [n_slices << plog] (zeroed): pieces of (slice, part) that have been swept into the L2 ahead of its probes; nullptr = no sweep
-	u64 filter_bytes;
 	u32 plog;        // log2 of the parts a slice is probed in (0: whole slices)
 };
-constexpr u32 PROBE_PF_PARTS = 32; // a slice is swept in this many parts, one per workgroup that comes to it
 
 __device__ __forceinline__ u32
 xcc_id()
@@ -403,7 +400,7 @@ probe_claim(u32* __restrict__ ctl, u32 xcd, u32 n_slices, u32 total, u32& sl, u3
 __global__ __launch_bounds__(PROBE_TPB) void
 k_bin_probe(ProbeArgs a)
 {
-	__shared__ u32 s_draw[2][4]; // {ok, slice, start, part of the slice to sweep}, double-buffered: one barrier per draw
+	__shared__ u32 s_draw[2][4]; // {ok, slice, start}, double-buffered: one barrier per draw
 	const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const u64 off_mask = (1ULL << a.slog) - 1;
 	const u32 xcd = a.force_xcc == PROBE_XCC_ANY ? xcc_id() : (a.force_xcc & 15u);
@@ -413,7 +410,6 @@ k_bin_probe(ProbeArgs a)
 	const u32 n_units = a.n_slices << a.plog; // (slice, part) pairs
 	const u32 part_shift = a.slog - a.plog;
 	u32 sl = NONE32, p = 0; // (thread 0: the draw made ahead; sl counts (slice, part) pairs)
-	u32 swept = NONE32;     // (thread 0: the slice this workgroup took a sweep ticket for last)
 	for (u32 it = 0;; it++) {
 		u32* d = s_draw[it & 1];
 		if (threadIdx.x == 0) {
@@ -421,12 +417,6 @@ k_bin_probe(ProbeArgs a)
 			d[0] = ok ? 1u : 0u;
 			d[1] = sl;
 			d[2] = p;
-			d[3] = NONE32;
-			if (ok && a.pf && sl != swept) {
-				// first draw of this workgroup from a new slice: take one part of it to sweep (below)
-				swept = sl;
-				d[3] = atomicAdd(&a.pf[sl], 1u);
-			}
 			if (ok) {
 				// draw the stretch after this one now: its round trip hides behind the probes
 				p = atomicAdd(&a.ctl[CTL_WORK + sl], PROBE_DRAW);
@@ -437,27 +427,6 @@ k_bin_probe(ProbeArgs a)
 			return;
 		}
 		const u32 dsl = d[1];
-		if (d[3] < PROBE_PF_PARTS) {
-			// A slice starts cold: its 2-4 MiB come in through the misses of the first probes, a 128-byte line per random
-			// gather at HBM latency, while every wavefront of the XCD waits.  The first workgroups that come to a slice
-			// therefore sweep one part of it each with coalesced 16-byte loads (plain loads: they stay in the L2) before
-			// they probe; the sum of the parts is the slice, in flight all at once.
-			const u64 unit_bytes = 1ULL << (part_shift - bsh);
-			const u64 part_bytes = unit_bytes / PROBE_PF_PARTS;
-			u64 lo = ((u64)dsl << (part_shift - bsh)) + (u64)d[3] * part_bytes;
-			u64 hi = lo + part_bytes < a.filter_bytes ? lo + part_bytes : a.filter_bytes;
-			lo = lo < hi ? lo : hi;
-			const uintptr_t base = reinterpret_cast<uintptr_t>(a.filter);
-			uintptr_t p0 = (base + lo + 15) & ~(uintptr_t)15, p1 = (base + hi) & ~(uintptr_t)15;
-			u32 acc = 0;
-			for (uintptr_t q = p0 + (uintptr_t)threadIdx.x * 16; q < p1; q += (uintptr_t)PROBE_TPB * 16) {
-				const uint4 v = *reinterpret_cast<const uint4*>(q);
-				acc ^= v.x ^ v.y ^ v.z ^ v.w;
-			}
-			if (acc == 0x9E3779B9u && a.n_slices == NONE32) {
-				a.ctl[CTL_NEXT] = acc; // (never true: keeps the loads)
-			}
-		}
 		const u32 at = d[2] + wave * PROBE_STEP;
 		if (at >= total) {
 			continue;

@@ -151,7 +151,7 @@ is_event_start(const u64* bitmap, u64 g, u32 grid)
 struct Best
 {
 	u32 edit_type; // 0 none, 1 substitution, 2 insertion, 3 deletion
-	u8 indel[12];
+	u8 indel[INDEL_BYTES];
 	u32 n_indel;
 	u8 sub_base;
 	u32 num_support;

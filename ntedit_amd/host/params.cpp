@@ -93,9 +93,9 @@ make_dev_params(
     nte::DevParams* out,
     bool counting)
 {
-	static const uint32_t num_tries[6] = { 0, 1, 5, 21, 85, 341 }; // ntedit.cpp:172
+	static const uint32_t num_tries[nte::MAX_INSERTION + 1] = { 0, 1, 5, 21, 85, 341 }; // ntedit.cpp:172
 	if (k < 12 || k > 200 || hash_num == 0 || hash_num > nte::MAX_HASHES || hp.jump == 0 ||
-	    hp.max_insertions > 5 || hp.max_deletions > 10 || hp.mode < 0 || hp.mode > 2) {
+	    hp.max_insertions > nte::MAX_INSERTION || hp.max_deletions > nte::MAX_DELETION || hp.mode < 0 || hp.mode > 2) {
 		return NTEDIT_E_ARG;
 	}
 	nte::DevParams d;

@@ -2,6 +2,7 @@
 nte_machine.h / render.cpp, tests/hostsim) against the oracle, byte for byte.
 Same configurations as the GPU parity test."""
 import filecmp
+import os
 
 import numpy as np
 
@@ -185,3 +186,33 @@ def test_filter_file_size_not_a_multiple_of_8(tmp_path, oracle_build):
     # and it is NOT what the rounded-up modulus gives
     H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "r"))
     assert not filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / "r_changes.tsv"), shallow=False)
+
+
+def _gap_case(tmp, gap, seed=91):
+    """a contig with a scaffold gap of `gap` Ns, errors right in front of and right behind it"""
+    rng = np.random.default_rng(seed)
+    truth = H.random_genome(rng, 30000)
+    H.write_fasta(os.path.join(tmp, "truth.fa"), [(b"t0", truth)])
+    H.mkbf([os.path.join(tmp, "truth.fa")], os.path.join(tmp, "t.bf"), k=25, hashes=3, nbytes=1 << 17)
+    d = bytearray(H.mutate(rng, truth, 1e-3, 2e-4, 2e-4))
+    cut = len(d) // 2
+    for p in (cut - 30, cut - 9, cut + 4, cut + 33):  # substitutions whose k-mers reach the gap
+        d[p] = ord("ACGT"[("ACGT".index(chr(d[p])) + 1) % 4])
+    draft = bytes(d[:cut]) + b"N" * gap + bytes(d[cut:])
+    H.write_fasta(os.path.join(tmp, "draft.fa"), [(b"scaffold1 with a gap", draft), (b"c2", H.mutate(rng, truth[:5000], 2e-3, 0, 0))])
+    return os.path.join(tmp, "draft.fa"), os.path.join(tmp, "t.bf")
+
+
+def test_scaffold_gap(tmp_path, oracle_build):
+    """A run of a million Ns with errors on both sides: an event that ends in front of the gap stops inside it as soon
+    as its state is clean (no k-mer in there is in the absent bitmap) instead of rolling through it base by base -- the
+    serial program's arrival behind the gap is the start of another event.  Same bytes as the oracle."""
+    draft, bf = _gap_case(str(tmp_path), 1_000_000)
+    for kw in (dict(), dict(mode=1, mask=1), dict(snv=1)):
+        hp = H.default_params(**kw)
+        H.run_oracle(draft, bf, hp, str(tmp_path / "o"))
+        rc, nev, nap = H.run_hostsim(H.read_fasta(draft), H.load_bf(bf), hp, str(tmp_path / "h"))
+        assert rc == 0 and nap > 10
+        for suf in ("_changes.tsv", "_edited.fa"):
+            assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("h" + suf)), shallow=False), (suf, kw)
+        assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))

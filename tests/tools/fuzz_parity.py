@@ -30,15 +30,26 @@ def random_config(rng):
         if rng.random() < p:
             flav.append(f)
     cbf = rng.random() < 0.15
+    # one case in eight from the corner round 4's two mismatches came from (and 131 GPU tests never visited): k >= 100 with a
+    # small -j -- subsets of 34..200 k-mers per position, beyond what a lane keeps in registers -- on a counting filter
+    # and / or with -s 1
+    bigk = rng.random() < 0.125
+    if bigk:
+        cbf = cbf or rng.random() < 0.6
     if cbf:
         flav = [f for f in flav if f != "sec"] + ["cbf"]
     k = int(rng.choice([12, 15, 20, 25, 25, 25, 31, 32, 33, 40, 55, 64, 96, 128, 200]))
     snv = rng.random() < 0.12
-    n = int(rng.integers(6000, 9000)) if snv else int(rng.integers(8000, 50000))
+    if bigk:
+        k = int(rng.choice([100, 128, 160, 200]))
+        snv = snv or not cbf or rng.random() < 0.5
+    n = int(rng.integers(6000, 9000)) if (snv or bigk) else int(rng.integers(8000, 50000))
     case = dict(n=n, contigs=int(rng.integers(1, 4)), k=k, hashes=int(rng.integers(1, 7)),
                 p_sub=float(rng.choice([5e-4, 2e-3, 1e-2, 3e-2])), p_ins=float(rng.choice([0, 3e-4, 2e-3, 5e-3])),
                 p_del=float(rng.choice([0, 3e-4, 2e-3, 5e-3])), flavor=" ".join(flav))
     slots_per_kmer = float(rng.choice([4, 8, 16, 40]))
+    if bigk and slots_per_kmer < 8:
+        slots_per_kmer = 8.0  # (a saturated filter at k >= 100 in mode 2 is minutes of oracle time per case)
     nb = max(1024, int(n * case["contigs"] * slots_per_kmer / 8))
     if rng.random() < 0.5:
         nb = 1 << int(np.ceil(np.log2(nb)))
@@ -60,6 +71,9 @@ def random_config(rng):
         par.update(min_threshold=int(rng.choice([1, 2, 3])), max_threshold=int(rng.choice([255, 255, 4, 200])))
     if snv:
         par["snv"] = 1
+    if bigk:
+        par["jump"] = int(rng.choice([1, 2, 3]))
+        par["mode"] = int(rng.choice([0, 0, 1]))
     if rng.random() < 0.3:
         par["start_grid"] = int(rng.choice([1, 2, 16, 64, 4096]))
     if rng.random() < 0.3:

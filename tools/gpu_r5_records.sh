@@ -13,5 +13,6 @@ bash tools/gpu_small.sh > gpurun_out/$T/small_shards.txt 2>&1
 SIZES="4294967296 4640000000 8589934592 17179869184" bash tools/gpu_bigfilter.sh > gpurun_out/$T/big_filters.txt 2>&1
 NTEDIT_HIP_DEBUG=1 python tools/gpu_outlier.py 2 2>&1 | grep -v "chunk 1/1\|binned chunk\|amdgpu.ids" > gpurun_out/$T/outlier_sequence.log
 NTEDIT_HIP_LIB=$PWD/ntedit_amd/libntedit_hip_prof.so NTEDIT_HIP_DEBUG=1 python bench.py --steps 1 --warmup 1 --no-regions --no-cpu-baseline --no-gather 2>&1 >/dev/null | grep -E "wave-kernel|inside failing|machine filter" > gpurun_out/$T/wave_kernel_phases.txt
+bash tools/gpu_reh.sh > gpurun_out/$T/rehearsal_n2.log 2>&1; cp gpurun_out/rehearsal_n2.json gpurun_out/$T/ 2>/dev/null
 bash tools/profile_gpu.sh r5 > gpurun_out/$T/profile_gpu.log 2>&1
 tail -3 gpurun_out/$T/gpu_tests.log; cut -c1-400 gpurun_out/$T/bench.json; cat gpurun_out/$T/small_shards.txt; cat gpurun_out/$T/fuzz.log

@@ -27,7 +27,10 @@ constexpr int ASSESS_MAX_WIN = ASSESS_TILE + 2 * 200 + 10 + 1 + 32; // k <= 200,
 // there on (2 table look-ups per position instead of 2k), keeps count of the accepted codes in front of it (the window
 // of a position has to hold k + win_len_in() of them), and asks Machine::assess_gate() where the absent bitmap has the
 // position.  Four lanes make one word of the run map.
-__global__ __launch_bounds__(ASSESS_TPB) void
+#ifndef NTE_ASSESS_MIN_BLOCKS
+#define NTE_ASSESS_MIN_BLOCKS 4 // blocks of 256 per CU the register allocation leaves room for (118 VGPRs as it falls out)
+#endif
+__global__ __launch_bounds__(ASSESS_TPB, NTE_ASSESS_MIN_BLOCKS) void
 k_assess(AssessArgs a)
 {
 	__shared__ __attribute__((aligned(16))) u64 s_tab[TAB_WORDS];
@@ -97,7 +100,8 @@ k_assess(AssessArgs a)
 		const bool plain = !__syncthreads_or(exotic ? 1 : 0);
 		u32 keep = abits;
 		if (plain && abits) {
-			MachineT<0> m(env);
+			MachineT<0> m(env); // (the general machine: an instantiation for -m 0 / no secondary filter / power-of-two sizes
+			                    // was built in round 5 and ran SLOWER, 40.5 against 35.7 ms per 250 Mbp with -s 1)
 			m.win_ok = true;
 			m.win_off = x0;
 			HashState hs = m.seed_from_window();

@@ -890,3 +890,31 @@ def test_scaffold_gap_is_not_walked(tmp_path, oracle_build):
             assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("g" + suf)), shallow=False), (suf, kw)
         print("\n[gap] 8 Mbp of N, %r: polish call %.1f ms (machine %.2f ms)" % (kw, ms, st.ms_machine), flush=True)
         assert st.ms_machine < 150.0, st.ms_machine
+
+
+def test_reserve_with_hostile_parameters(tmp_path, oracle_build):
+    """ntedit_hip_reserve runs an internal batch of random bases through whatever the caller configured.  With -m 2, -a 1,
+    an event start at every absent position and a tiny event budget (fuzz seed 42424200069: reserve used to fail with
+    "event machine ran out of room" there -- a megabase of unknown draft was 10 GB of mask records) it must neither fail
+    nor crawl, and the batch polished after it must be the oracle's."""
+    import time
+    case_kw = {'n': 11612, 'contigs': 3, 'k': 25, 'hashes': 1, 'p_sub': 0.002, 'p_ins': 0.005, 'p_del': 0.0003,
+               'flavor': 'iupac rep sec', 'bfbytes': 174386}
+    par_kw = {'mode': 2, 'mask': 1, 'jump': 1, 'max_insertions': 0, 'max_deletions': 1, 'min_contig_len': 0,
+              'missing_threshold': 25.0, 'edit_threshold': 25.0, 'start_grid': 1, 'event_budget': 600}
+    case = H.make_case(str(tmp_path), 42424200069, **case_kw)
+    hp = H.default_params(**par_kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), case["rep"])
+    pol = _fresh(force_rounds=False)
+    try:
+        _load_filters(pol, case)
+        pol.set_params(_hip_params(**par_kw))
+        t0 = time.time()
+        pol.reserve(64 << 20, 1 << 16, on_device=2)
+        dt = time.time() - t0
+        pol.polish_records(H.read_fasta(case["draft"]), str(tmp_path / "g"))
+    finally:
+        pol.close()
+    for suf in ("_changes.tsv", "_edited.fa"):
+        assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("g" + suf)), shallow=False), suf
+    assert dt < 20.0, "reserve took %.1f s" % dt

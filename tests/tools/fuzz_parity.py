@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--minutes", type=float, default=0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--first", type=int, default=0, help="start at this iteration of the seed (re-run one case: --first N --iters N+1)")
     ap.add_argument("--keep", default=os.path.join(ROOT, "gpurun_out", "fuzz_failures"))
     args = ap.parse_args()
     H.build_oracle()
@@ -98,7 +99,7 @@ def main():
         H.build_hostsim()
     t_end = time.time() + args.minutes * 60 if args.minutes else None
     bad = 0
-    it = 0
+    it = args.first
     t_start = time.time()
     while it < args.iters or (t_end and time.time() < t_end):
         if t_end and time.time() >= t_end:

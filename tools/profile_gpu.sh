@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="${@:---bases 3e9 --steps 2 --warmup 1 --no-cpu-baseline --no-gather --no-regions}"
+ARGS="${@:---bases 3e9 --steps 2 --warmup 1 --no-cpu-baseline --no-gather --no-regions --no-reserve}"  # (--no-reserve: its warm-up batch would count as a fourth, tiny launch of every kernel)
 # pass 1: kernel trace + stats (no counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace.err
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;

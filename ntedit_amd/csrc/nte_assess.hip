@@ -127,7 +127,11 @@ k_assess(AssessArgs a)
 			}
 			// (Probing the candidates of a lane's 16 positions together -- 16 gathers per filter level in flight instead of
 			// three or four -- was built and measured: 70 instead of 35 ms per 250 Mbp with -s 1.  The wavefronts in flight
-			// already keep the memory system busy; the unrolled 16-wide bookkeeping only added instructions.)
+			// already keep the memory system busy; the unrolled 16-wide bookkeeping only added instructions.  Round 5, same
+			// question at a smaller scale: the gate alone for TWO positions at a time (6-8 gathers per level) 38.9 against
+			// 35.9 ms; 6 / 8 waves per SIMD (80 / 64 registers) 41.1 / 43.5 ms; an instantiation of the machine for the
+			// configuration 40.5 ms.  The kernel's TCPs wait for misses 87 % of the time at 29 G fabric requests/s
+			// (profiles/r5_assess_counters.txt): what it lacks is not requests in flight.)
 		}
 		// four lanes = one word
 		const u32 k1 = (u32)__shfl_down((int)keep, 1, 64), k2 = (u32)__shfl_down((int)keep, 2, 64), k3 = (u32)__shfl_down((int)keep, 3, 64);

@@ -66,9 +66,43 @@ class HipBackend:
     def screen(self, blob):
         return self.pol.screen(blob)
 
+    def _pinned_batch(self, entries):
+        """the batch layout of pack_batch, written straight into page-locked memory (ntedit_hip_host_alloc): the batch then
+        crosses PCIe asynchronously, in pieces, under the screening -- from ordinary memory the runtime stages it through
+        its own buffers first (a rank's 375 Mbp: ~35 ms against ~10)"""
+        import numpy as np
+        total = sum(len(e[1]) + 1 for e in entries)
+        lib = self.pol._lib
+        if total > getattr(self, "_pin_cap", 0):
+            if getattr(self, "_pin_ptr", None):
+                lib.ntedit_hip_host_free(ctypes.c_void_p(self._pin_ptr))
+            self._pin_ptr = lib.ntedit_hip_host_alloc(total + total // 8 + 4096)
+            self._pin_cap = total + total // 8 + 4096 if self._pin_ptr else 0
+        if not getattr(self, "_pin_ptr", None):
+            return None
+        buf = np.ctypeslib.as_array((ctypes.c_uint8 * total).from_address(self._pin_ptr))
+        offs, lens, pos = [], [], 0
+        for _, seq, _ in entries:
+            n = len(seq)
+            buf[pos:pos + n] = np.frombuffer(seq, dtype=np.uint8)
+            buf[pos + n] = 10
+            offs.append(pos)
+            lens.append(n)
+            pos += n + 1
+        return buf, np.array(offs, dtype=np.uint64), np.array(lens, dtype=np.uint32)
+
+    def close(self):
+        if getattr(self, "_pin_ptr", None):
+            self.pol._lib.ntedit_hip_host_free(ctypes.c_void_p(self._pin_ptr))
+            self._pin_ptr, self._pin_cap = None, 0
+
     def polish(self, entries, fa, tsv, vcf, append):
         names = [e[0] for e in entries]
-        blob, offs, lens, _ = pack_batch([(e[0], e[1]) for e in entries], 0)
+        pinned = self._pinned_batch(entries)
+        if pinned is not None:
+            blob, offs, lens = pinned
+        else:
+            blob, offs, lens, _ = pack_batch([(e[0], e[1]) for e in entries], 0)
         res = self.pol.polish_batch(blob, offs, lens)
         # the renderer's own predicate, asked before anything is written (a refused entry would leave the shard
         # files half-written): a cut that is not event-free is polished again joined with its successor
@@ -206,6 +240,7 @@ def main(argv=None):
         sys.stdout.flush()
     if annot.value:
         pol._lib.ntedit_hip_annot_free(annot)
+    backend.close()
     pol.close()
     if dist.is_initialized():
         dist.destroy_process_group()

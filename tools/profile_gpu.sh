@@ -44,8 +44,8 @@ import json, re, sys
 txt, out, tag = open(sys.argv[1]).read(), sys.argv[2], sys.argv[3]
 line = json.loads(open(sys.argv[4]).readline())  # (the bench line of the traced run: workload and build of the kernels)
 agg = {}
-for line in txt.splitlines():
-    m = re.match(r"(.*?) dispatches=(\d+) (.*)", line)
+for row in txt.splitlines():
+    m = re.match(r"(.*?) dispatches=(\d+) (.*)", row)
     if not m or "nte::" not in m.group(1):
         continue
     name = re.sub(r"^void ", "", m.group(1)).split("(")[0].replace("nte::", "")

@@ -322,7 +322,10 @@ struct BinArgs
 #endif
 constexpr int PROBE_TPB = NTE_PROBE_TPB;
 constexpr int PROBE_WAVES = PROBE_TPB / 64;
-constexpr int PROBE_PER = 8;                  // records per lane and step, all in flight together
+#ifndef NTE_PROBE_PER
+#define NTE_PROBE_PER 8
+#endif
+constexpr int PROBE_PER = NTE_PROBE_PER;      // records per lane and step, all in flight together
 constexpr int PROBE_STEP = 64 * PROBE_PER;    // records per step of a wavefront
 constexpr u32 PROBE_DRAW = PROBE_STEP * PROBE_WAVES; // records per draw of a workgroup
 constexpr u32 CTL_NEXT = 0, CTL_CUR = 1, CTL_WORK = 32;

@@ -633,3 +633,15 @@ hostsim_fasta_map_dump(const char* in_path, const char* out_path, unsigned threa
 	fclose(o);
 	return (int)m.records();
 }
+
+// TEST-ONLY: nte::filter_slot (the device's hv % slots without a division) for n hash values
+extern "C" void
+hostsim_filter_slots(unsigned long long slots, const unsigned long long* hv, unsigned long long n, unsigned long long* out)
+{
+	nte::Filter f;
+	memset(&f, 0, sizeof f);
+	nte::filter_set_size(f, slots);
+	for (unsigned long long i = 0; i < n; i++) {
+		out[i] = nte::filter_slot(f, hv[i]);
+	}
+}

@@ -205,3 +205,25 @@ def test_btllib_kit_our_side_matches_the_oracle(tmp_path, oracle_build):
             if "N" not in s[i:i + 25]:  # (the screening bitmap only speaks about k-mers of accepted bases)
                 assert got == 1 - int(absent[i]), i
         assert next(qi) == "--"
+
+
+def test_filter_slot_is_the_modulo(oracle_build):
+    """nte::filter_slot -- the device's `hash % slots` without a division (nte_common.h): the general reciprocal form and the
+    short form for filters of 2^32 .. 2^40 slots -- against Python's % on random and adversarial hash values, for sizes on
+    both sides of every boundary (btllib: `hash % array_bits`, ntedit.cpp:368-371)."""
+    import ctypes
+    lib = ctypes.CDLL(H.build_hostsim())
+    rng = np.random.default_rng(5)
+    sizes = [1000003, (1 << 32) - 5, (1 << 32) + 1, (1 << 32) + 2, 37_120_000_000, 4_640_000_000 * 8, (1 << 36) + 12345,
+             (1 << 40) - 1, (1 << 40) + 7, 3 * (1 << 33), (1 << 35), 100000007 * 8, 2 ** 41 + 11]
+    for m in sizes:
+        hv = rng.integers(0, 1 << 64, 200000, dtype=np.uint64)
+        edge = [0, 1, m - 1, m, m + 1, 2 * m - 1, 2 * m, 3 * m - 1, (1 << 64) - 1, (1 << 64) - m, ((1 << 64) // m) * m - 1,
+                ((1 << 64) // m) * m, (1 << 32) - 1, 1 << 32, (1 << 63) + m]
+        hv[:len(edge)] = np.array([e % (1 << 64) for e in edge], dtype=np.uint64)
+        out = np.zeros_like(hv)
+        lib.hostsim_filter_slots(ctypes.c_ulonglong(m), hv.ctypes.data_as(ctypes.c_void_p), ctypes.c_ulonglong(len(hv)),
+                                 out.ctypes.data_as(ctypes.c_void_p))
+        want = np.array([int(x) % m for x in hv[:len(edge)]], dtype=np.uint64)
+        assert (out[:len(edge)] == want).all(), m
+        assert (out == hv % np.uint64(m)).all(), m

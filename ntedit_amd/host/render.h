@@ -31,7 +31,10 @@ struct RenderOptions
 	bool snv = false;               // -s 1: "no edit" substitution records go to the VCF only
 	const Annotations* annot = nullptr;
 	unsigned threads = 0;           // work units rendered concurrently (0 = up to 8, 1 = in the calling thread)
-	unsigned unit_bases = 1u << 20; // a work unit = consecutive contigs of about this many bases
+#ifndef NTE_RENDER_UNIT_BASES
+#define NTE_RENDER_UNIT_BASES (1u << 20)
+#endif
+	unsigned unit_bases = NTE_RENDER_UNIT_BASES; // a work unit = consecutive contigs of about this many bases (and the size of a large contig's parts)
 	// > 0: contigs of several units are rendered in parts, cut in front of events that no earlier event's run comes within
 	// this many bases of (k + max deletions + slack: what an event may touch behind the end of its run); 0: whole contigs
 	unsigned part_margin = 0;

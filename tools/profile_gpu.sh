@@ -61,7 +61,7 @@ for name, d in agg.items():
                      "fetch_size_kib_per_launch": d.get("FETCH_SIZE", 0) / n,
                      "write_bytes_per_launch": d["WRITE_SIZE"] * 1024 / n,
                      "tcc_hit_rate": d["TCC_HIT_sum"] / max(1.0, d["TCC_HIT_sum"] + d["TCC_MISS_sum"]) if "TCC_HIT_sum" in d else None}
-json.dump({"source": "profiles/%s_pmc_summary.txt (rocprofv3 --pmc, one counter group per run; reads = TCC_EA0_RDREQ x 64 B, writes = WRITE_SIZE KiB x 1024)" % tag,
+json.dump({"source": "profiles/%s_bench_3Gbp_pmc_summary.txt (rocprofv3 --pmc, one counter group per run; reads = TCC_EA0_RDREQ x 64 B, writes = WRITE_SIZE KiB x 1024)" % tag,
            "workload_bytes": line["config"]["workload_bytes"], "build_id": line.get("build_id"),
            "kernels": res}, open(out, "w"), indent=1)
 PY

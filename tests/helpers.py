@@ -434,6 +434,25 @@ def make_case(tmp, seed, n=60000, p_sub=2e-3, p_ins=3e-4, p_del=3e-4, k=25, hash
     return out
 
 
+def make_sweep_rich_case(tmp, seed=5, n=30000):
+    """A counting-filter case in which position after position needs an indel sweep (bench.py --counting in
+    small): a small filter, an error-rich draft, and the counters that are not zero rewritten to 1..4 by slot index,
+    so that -p 2 cuts into the k-mers that are there.  Returns make_case's dict."""
+    case = make_case(tmp, seed, n=n, contigs=2, flavor="cbf", bfbytes=1 << 14, p_sub=1e-2, p_ins=3e-3, p_del=3e-3)
+    raw = open(case["bf"], "rb").read()
+    cut = raw.index(b"[HeaderEnd]\n") + len(b"[HeaderEnd]\n")
+    old = np.frombuffer(raw[cut:], dtype=np.uint8)
+    idx = np.arange(old.size, dtype=np.uint64)
+    val = (1 + ((idx * np.uint64(2654435761) + np.uint64(7)) >> np.uint64(13)) % np.uint64(4)).astype(np.uint8)
+    with open(case["bf"], "wb") as f:
+        f.write(raw[:cut] + np.where(old != 0, val, 0).astype(np.uint8).tobytes())
+    return case
+
+
+SWEEP_RICH_PARAMS = [dict(), dict(event_budget=8), dict(start_grid=16, max_insertions=2, max_deletions=3),
+                     dict(jump=1, event_budget=100), dict(max_threshold=3)]
+
+
 # (case kwargs, parameter kwargs) pairs shared by the hostsim (CPU) and GPU parity tests
 PARITY_CONFIGS = [
     (dict(), dict()),

@@ -918,3 +918,25 @@ def test_reserve_with_hostile_parameters(tmp_path, oracle_build):
     for suf in ("_changes.tsv", "_edited.fa"):
         assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("g" + suf)), shallow=False), suf
     assert dt < 20.0, "reserve took %.1f s" % dt
+
+
+@pytest.mark.parametrize("kw", H.SWEEP_RICH_PARAMS)
+def test_sweep_rich_counting_filter(tmp_path, oracle_build, kw):
+    """Counting filter, -p 2 cutting into the k-mers that are there, an error-rich draft: runs in which position after
+    position needs an indel sweep, behind substitutions as well (bench.py --counting in small; a tenth of the events of
+    such a batch are most of its machine time).  All events in one round and in rounds; same bytes as the oracle."""
+    case = H.make_sweep_rich_case(str(tmp_path))
+    recs = H.read_fasta(case["draft"])
+    hp = H.default_params(min_threshold=2, **kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"))
+    for rounds in (False, True):
+        pol = _fresh(force_rounds=rounds)
+        try:
+            pol.load_filter_file(case["bf"])
+            pol.set_params(_hip_params(min_threshold=2, **kw))
+            pol.polish_records(recs, str(tmp_path / ("g%d" % rounds)))
+        finally:
+            pol.close()
+        for suf in ("_changes.tsv", "_edited.fa"):
+            assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("g%d%s" % (rounds, suf))), shallow=False), (suf, kw, rounds)
+        assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / ("g%d_variants.vcf" % rounds)))

@@ -216,3 +216,18 @@ def test_scaffold_gap(tmp_path, oracle_build):
         for suf in ("_changes.tsv", "_edited.fa"):
             assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("h" + suf)), shallow=False), (suf, kw)
         assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))
+
+
+@pytest.mark.parametrize("kw", H.SWEEP_RICH_PARAMS[:3])
+def test_sweep_rich_counting_filter(tmp_path, oracle_build, kw):
+    """Counting filter, -p 2 cutting into the k-mers that are there, an error-rich draft: runs in which position after
+    position needs an indel sweep, behind substitutions as well (bench.py --counting in small; a tenth of the events of
+    such a batch are most of its machine time).  Same bytes as the oracle."""
+    case = H.make_sweep_rich_case(str(tmp_path))
+    hp = H.default_params(min_threshold=2, **kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"))
+    rc, nev, nap = H.run_hostsim(H.read_fasta(case["draft"]), H.load_bf(case["bf"]), hp, str(tmp_path / "h"))
+    assert rc == 0 and nap > 10
+    for suf in ("_changes.tsv", "_edited.fa"):
+        assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("h" + suf)), shallow=False), (suf, kw)
+    assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))

@@ -24,12 +24,12 @@ CLAMP = ctypes.CDLL(os.path.join(ROOT, "ntedit_amd", "libntedit_hip.so")).ntedit
 CLAMP.restype = None
 
 
-def random_config(rng):
+def random_config(rng, force_cbf=False):
     flav = []
     for f, p in (("N", 0.3), ("lower", 0.2), ("iupac", 0.15), ("exotic", 0.1), ("rep", 0.2), ("sec", 0.2)):
         if rng.random() < p:
             flav.append(f)
-    cbf = rng.random() < 0.15
+    cbf = rng.random() < 0.15 or force_cbf
     # one case in eight from the corner round 4's two mismatches came from (and 131 GPU tests never visited): k >= 100 with a
     # small -j -- subsets of 34..200 k-mers per position, beyond what a lane keeps in registers -- on a counting filter
     # and / or with -s 1
@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--first", type=int, default=0, help="start at this iteration of the seed (re-run one case: --first N --iters N+1)")
+    ap.add_argument("--cbf", action="store_true", help="counting filters only")
     ap.add_argument("--keep", default=os.path.join(ROOT, "gpurun_out", "fuzz_failures"))
     args = ap.parse_args()
     H.build_oracle()
@@ -107,7 +108,7 @@ def main():
         seed = args.seed * 100000 + it
         it += 1
         rng = np.random.default_rng(seed)
-        case_kw, par_kw = random_config(rng)
+        case_kw, par_kw = random_config(rng, args.cbf)
         tmp = tempfile.mkdtemp(prefix="ntefuzz_")
         why = None
         try:

@@ -559,7 +559,6 @@ struct SubRange
 	uint32_t pa, pb; // pb = the contig's length for its last part
 	bool first, last;
 };
-constexpr uint32_t PART_MARGIN_EXTRA = 48; // + k: what an event may touch behind the end of its run (tested base, indel look-ahead)
 
 // events [ev, ev_end) of contig ci -> o
 void

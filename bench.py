@@ -62,6 +62,9 @@ def parse():
                     help="N=1 side line: -s 1 (every position re-assessed, ntedit.cpp:1806,1865; -i/-d 0)")
     ap.add_argument("--counting", action="store_true",
                     help="N=1 side line: a counting filter of --filter-bytes 8-bit counters (synthetic contents), -p 2")
+    ap.add_argument("--structure", choices=("iid", "genome"), default="iid",
+                    help="truth genome: i.i.d. bases (SURVEY 8d, the headline) or with repeat arrays, repeat families, segmental "
+                         "duplications and stretches the filter does not hold (synth.GenomeStructure; a side line)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="ntedit_hip_set_tuning knob (repeatable; none of them changes a result)")
     ap.add_argument("--no-reserve", action="store_true",
@@ -540,7 +543,7 @@ def main():
     job = SyntheticJob(pol, args.bases, k=args.k, hash_num=args.hashes,
                        filter_bytes=args.filter_bytes // 8 if args.counting else args.filter_bytes,
                        seed=20251031, draft_seed=20251032, device=dev, build_filter=build,
-                       contig_len=args.contig_len)
+                       contig_len=args.contig_len, structure=args.structure)
     counters = None
     if args.counting:
         # the plain filter's bit slots become 8-bit counters (1..4 for every truth k-mer); -p 2
@@ -669,12 +672,15 @@ def main():
                              args.k, args.filter_bytes, args.hashes,
                              "screen kernel only" if args.screen_only else
                              "screen + event extraction + event machine + edit records to host") +
+                            (", GENOME-LIKE truth (" + ", ".join("%s %.1f%%" % (kk, 100.0 * vv / job.n_bases) for kk, vv in
+                                                                job.structure.bases.items()) + " of the bases)"
+                             if job.structure is not None else "") +
                             (", SNV mode (-s 1, -i 0 -d 0)" if args.snv else "") +
                             (", COUNTING filter (8-bit counters, synthetic contents 1..4, -p 2)" if args.counting else ""),
                 "total_bases": total_bases,
                 "workload_bytes": int(my_bytes),  # (batch bytes of this rank: what the counter records under profiles/ are keyed by)
                 "k": args.k, "hashes": args.hashes, "filter_bytes": args.filter_bytes,
-                "snv": bool(args.snv), "counting": bool(args.counting),
+                "snv": bool(args.snv), "counting": bool(args.counting), "structure": args.structure,
                 "parallelism": "ONE draft sharded over %d rank(s) by bases (LPT over pieces; %d contig(s) cut into "
                                "segments), filter broadcast once over RCCL (untimed)" % (world, n_cut),
                 "shard_bases": shard_bases,

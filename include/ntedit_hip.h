@@ -211,7 +211,10 @@ typedef struct ntedit_hip_stats
 	float ms_partition;       /* binned: HIP-event time of the partition kernels (count + scan + scatter), sum */
 	float ms_probe;           /* binned: HIP-event time of the k_bin_probe launches, sum */
 	uint32_t events_skipped;  /* events not run because they start inside their cluster primary's run */
-	uint32_t reserved;
+	uint32_t screen_chunks_direct; /* binned: record chunks whose overflow list ran out and that k_screen screened again
+	                                  (a draft of very few distinct k-mers; 0 on anything like a genome) */
+	uint64_t screen_overflow_records; /* binned: entries of the overflow list handed out (blocks of 256 per partition
+	                                     wavefront): probes of repeated k-mers that did not fit their slice's run */
 } ntedit_hip_stats;
 int ntedit_hip_result_stats(const ntedit_hip_result* r, ntedit_hip_stats* s);
 
@@ -380,7 +383,8 @@ void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
  * timings.  Keys:
  *   screening   "screen_mode" (overrides params.screen_mode), "bin_chunk" (k-mer starts per record chunk of the
  *               partitioned screening), "bin_cap_percent" (record-run capacity in percent of the expectation: forces the
- *               overflow list), "bin_fallback" (1: direct kernel from now on, as after a lost overflow), "bin_scatter"
+ *               overflow list), "bin_ovf_cap" (entries of the overflow list: forces a list that runs out, i.e. record chunks
+ *               screened again by the direct kernel), "bin_fallback" (1: the direct kernel, like "screen_mode" 1), "bin_scatter"
  *               (1: the barrier-free partition kernel, kept as the second implementation the tests compare),
  *               "force_xcc" (x + 1: the probe stage behaves as if every wavefront ran on XCD x), "bin_timing"
  *   batches     "chunk_bytes" (pipeline chunk size), "h2d_piece" (bytes per host-to-device piece)

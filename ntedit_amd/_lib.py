@@ -57,7 +57,8 @@ class Stats(ctypes.Structure):
         ("ms_partition", ctypes.c_float),
         ("ms_probe", ctypes.c_float),
         ("events_skipped", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32),
+        ("screen_chunks_direct", ctypes.c_uint32),
+        ("screen_overflow_records", ctypes.c_uint64),
     ]
 
 

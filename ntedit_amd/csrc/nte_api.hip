@@ -95,14 +95,24 @@ struct ntedit_hip_ctx
 	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters, deferred;
 	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps, ws_win;
 	DevBuf offs, lens;
-	DevBuf bin_records, bin_fill, bin_ctl, bin_ovf, bin_lost; // the binned screening: records, run fills, probe control words, overflow list
+	DevBuf bin_records, bin_fill, bin_ctl, bin_ovf, bin_state; // the binned screening: records, run fills, probe control words, overflow list, chunk flags
+	struct BinRange
+	{
+		u64 begin, end;  // k-mer starts of one record chunk
+		bool recovered;  // its overflow list ran out and the direct kernel has screened it again
+	};
+	std::vector<BinRange> bin_ranges; // the record chunks of the current call, in launch order (bin_state's flags)
+	std::vector<u32> bin_flags_host;
+	u32 bin_chunks_direct = 0;        // chunks of the current call the direct kernel had to screen again
+	u64 bin_ovf_entries = 0;          // overflow entries handed out in the current call (as of the last bin_recover)
 	hipStream_t stream_copy = nullptr; // H2D pieces of a host batch that is polished in pipeline chunks (stream2 runs the event machine then)
-	bool bin_fallback = false;        // an overflow list overflowed: this context screens with the direct kernel from now on
 	struct Tuning                     // ntedit_hip_set_tuning(): test / tuning knobs, none of which can change a result
 	{
 		u32 screen_mode = 0;     // overrides params.screen_mode when not 0
 		u64 bin_chunk = 0;       // k-mer starts per record chunk of the binned screening (tests: several chunks)
 		u32 bin_cap_percent = 0; // run capacity in percent of the expected records (tests: force the overflow list)
+		u64 bin_ovf_cap = 0;     // entries of the overflow list (tests: a list that runs out; 0: an eighth of the chunk's records)
+		u32 bin_fallback = 0;    // 1: the direct kernel whatever the sizes (as "screen_mode" 1; kept for callers of round 5)
 		u32 force_xcc = 0;       // x + 1: every probe wavefront pretends to run on XCD x (tests)
 		u32 bin_timing = 0;      // per-stage times of the binned screening on stderr
 		u64 chunk_bytes = 0;     // pipeline chunk size (tests: many chunks)

@@ -231,6 +231,49 @@ def test_binned_overflow_list(tmp_path, percent, scatter, oracle_build):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("scatter", [0, 1])
+def test_binned_overflow_list_runs_out(tmp_path, scatter, oracle_build):
+    """an overflow list that is too small for what the runs send it (round 6: the list is handed out in blocks of 256
+    entries per partition wavefront, one global atomic per block): the record chunks that lost probes -- and only
+    those -- are screened again by the direct kernel before anything reads the bitmap; nothing is remembered, the next
+    call is back on the partitioned pipeline.  Bitmap and polished files identical to the oracle's."""
+    import ntedit_amd
+    case = H.make_case(str(tmp_path), 4850 + scatter, bfbytes=1 << 26, n=200000, contigs=3, flavor="N rep")
+    bf = H.load_bf(case["bf"])
+    recs = H.read_fasta(case["draft"])
+    blob, offs, lens, names = H.pack_batch(recs)
+    want = H.oracle_screen(blob, bf)
+    hp = H.default_params()
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"), case["rep"])
+    pol = _fresh()
+    try:
+        pol.set_filter(bf["data"], bf["hash_num"], bf["k"])
+        pol.set_params(ntedit_amd.default_params(screen_mode=2))
+        pol.set_tuning("bin_scatter", scatter)
+        pol.set_tuning("bin_cap_percent", 5)
+        pol.set_tuning("bin_chunk", 3 * 16384)
+        pol.set_tuning("bin_ovf_cap", 4096)          # 16 blocks: every chunk runs out
+        assert np.array_equal(pol.screen(blob), want)
+        st = pol.polish_records(recs, str(tmp_path / "g"))
+        assert st.screen_binned and st.screen_chunks_direct == st.screen_launches and st.screen_launches >= 4
+        pol.set_tuning("bin_ovf_cap", 120000)        # some chunks fit, some do not
+        assert np.array_equal(pol.screen(blob), want)
+        st_mixed = pol.polish_records(recs, str(tmp_path / "g1"))
+        pol.set_tuning("bin_ovf_cap", 0)             # the list at its real size: nothing is lost, nothing was remembered
+        assert np.array_equal(pol.screen(blob), want)
+        st2 = pol.polish_records(recs, str(tmp_path / "g2"))
+        assert st2.screen_binned and st2.screen_chunks_direct == 0 and st2.screen_overflow_records > 0
+        pol.set_tuning("bin_cap_percent", 0)         # and the runs at their real size: no overflow on this draft
+        st3 = pol.polish_records(recs, str(tmp_path / "g3"))
+        assert st3.screen_binned and st3.screen_chunks_direct == 0
+    finally:
+        pol.close()
+    print("chunks re-screened with a list of 120000 entries: %d of %d" % (st_mixed.screen_chunks_direct, st_mixed.screen_launches))
+    for g in ("g", "g1", "g2", "g3"):
+        assert filecmp.cmp(str(tmp_path / "o_changes.tsv"), str(tmp_path / (g + "_changes.tsv")), shallow=False)
+        assert filecmp.cmp(str(tmp_path / "o_edited.fa"), str(tmp_path / (g + "_edited.fa")), shallow=False)
+
+
 def test_binned_homopolymer_draft(tmp_path, oracle_build):
     """a draft of very few distinct k-mers (homopolymer and dinucleotide runs): all probes of a workgroup meet a
     handful of rings and runs -- ring waits, run overflow -- and the bitmap is still the oracle's"""
@@ -568,6 +611,32 @@ def test_full_size_nonpow2_filter_every_contig(tmp_path, oracle_build, capsys):
         assert st.screen_binned
         assert 0.8e-3 * job.n_bases < st.substitutions < 1.2e-3 * job.n_bases
         assert st.insertions > 0 and st.deletions > 0
+    finally:
+        pol.close()
+
+
+def test_genome_like_3gbp_every_contig(tmp_path, oracle_build, capsys):
+    """A draft that looks like an assembly (synth.GenomeStructure: ~3 % simple-sequence arrays, ~3 % satellite arrays, ~5 %
+    dispersed repeat families, ~2 % segmental duplications, ~0.5 % stretches the filter does not hold) at BASELINE's
+    headline size: the partitioned screening stays on (its overflow list takes the repeats' probes, no record chunk is
+    lost), and EVERY contig is byte-identical to the oracle's output."""
+    import ntedit_amd
+    from ntedit_amd.synth import SyntheticJob
+
+    total = float(os.environ.get("NTEDIT_FULL_BASES", "3e9"))
+    fbytes = int(os.environ.get("NTEDIT_FULL_FILTER", str(1 << 32)))
+    pol = ntedit_amd.Polisher(0)
+    try:
+        pol.set_params(ntedit_amd.default_params())
+        job = SyntheticJob(pol, total, k=25, hash_num=3, filter_bytes=fbytes, structure="genome")
+        pol.reserve(job.n_bytes, len(job.lens), on_device=1)
+        st, host, names = _compare_every_contig(pol, job, tmp_path, "genome3g", capsys)
+        with capsys.disabled():
+            print("[genome3g] structure (bases): %s; overflow entries %d, record chunks re-screened directly %d of %d"
+                  % (job.structure.bases, st.screen_overflow_records, st.screen_chunks_direct, st.screen_launches), flush=True)
+        assert st.screen_binned and st.screen_chunks_direct == 0
+        assert st.screen_overflow_records > 1_000_000  # (the simple-sequence arrays)
+        assert st.substitutions > 0.5e-3 * job.n_bases and st.insertions > 0 and st.deletions > 0
     finally:
         pol.close()
 

@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--structure", choices=("iid", "genome"), default="iid",
                     help="truth genome: i.i.d. bases (SURVEY 8d, the headline) or with repeat arrays, repeat families, segmental "
                          "duplications and stretches the filter does not hold (synth.GenomeStructure; a side line)")
+    ap.add_argument("--structure-fractions", default="", help="JSON: shares of single classes of --structure genome, e.g. "
+                    "'{\"novel\": 0}' (diagnosis)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="ntedit_hip_set_tuning knob (repeatable; none of them changes a result)")
     ap.add_argument("--no-reserve", action="store_true",
@@ -543,7 +545,8 @@ def main():
     job = SyntheticJob(pol, args.bases, k=args.k, hash_num=args.hashes,
                        filter_bytes=args.filter_bytes // 8 if args.counting else args.filter_bytes,
                        seed=20251031, draft_seed=20251032, device=dev, build_filter=build,
-                       contig_len=args.contig_len, structure=args.structure)
+                       contig_len=args.contig_len, structure=args.structure,
+                       structure_fractions=json.loads(args.structure_fractions) if args.structure_fractions else None)
     counters = None
     if args.counting:
         # the plain filter's bit slots become 8-bit counters (1..4 for every truth k-mer); -p 2

@@ -389,7 +389,8 @@ void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
  *               "force_xcc" (x + 1: the probe stage behaves as if every wavefront ran on XCD x), "bin_timing"
  *   batches     "chunk_bytes" (pipeline chunk size), "h2d_piece" (bytes per host-to-device piece)
  *   machine     "inline_tries", "no_rounds", "force_rounds", "no_early_copy", "lanes" (runs of failing positions one
- *               position per lane: 0 off, 1 in the clean state, 2 also behind substitutions), "defer_run" (hand-over
+ *               position per lane: 0 off, 1 in the clean state, 2 also behind substitutions), "defer_fail" (failing positions after which the thread-per-event launch hands an event
+ *               over), "defer_run" (hand-over
  *               threshold of the thread-per-event launch), "assess" (the run map: 0 never, 1 always; default: with -s 1
  *               and counting filters), "machine_cfg" (0: the general instantiation of the machine kernels)
  * (The measured-and-rejected variants of round 3 -- record chunks partitioned while the previous one is probed, slices

@@ -122,6 +122,7 @@ struct ntedit_hip_ctx
 		u32 machine_cfg = ~0u;   // 0: always the general instantiation of the machine kernels (~0: the most specific one)
 		u32 lanes = ~0u;         // DevParams::lanes (~0: default)
 		u32 defer_run = ~0u;     // DevParams::defer_run (~0: default)
+		u32 defer_fail = ~0u;    // DevParams::defer_fail (~0: default)
 		u32 no_rounds = 0, no_early_copy = 0;
 		u32 force_rounds = 0;     // event rounds whatever the number of events (tests: small inputs)
 		u32 bin_scatter = 0;      // partition kernel: 0 barrier-phased (k_wc_scatter_b), 1 barrier-free (k_wc_scatter)
@@ -308,6 +309,9 @@ refresh_params(ntedit_hip_ctx* c)
 	}
 	if (c->tune.defer_run != ~0u) {
 		c->dp.defer_run = c->tune.defer_run;
+	}
+	if (c->tune.defer_fail != ~0u) {
+		c->dp.defer_fail = c->tune.defer_fail;
 	}
 	if (!c->d_tab) {
 		HIP_TRY(c, hipMalloc((void**)&c->d_tab, TAB_WORDS * sizeof(u64)));

@@ -360,6 +360,8 @@ struct DevParams
 	                   // (0 off, 1 in the clean state, 2 also while the window holds substituted bases; nte_machine.h)
 	u32 defer_run;     // thread-per-event launch: an event whose clean position ends without an edit and whose absent run
 	                   // goes on for at least this many positions is handed to the wavefront-per-event launch (0 = never)
+	u32 defer_fail;    // thread-per-event launch: an event that has gone through this many failing positions (a chain of
+	                   // edits in repetitive sequence: one lane at work, 63 waiting for it) goes there as well (0 = never)
 	u64 mul[MAX_HASHES]; // mul[i] = i ^ (k * MULTISEED), i >= 1
 };
 

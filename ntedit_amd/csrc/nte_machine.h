@@ -44,6 +44,13 @@ extern WorkCounters g_wc;
 // -DNTE_PROFILE): shader cycles per phase, summed over events into g_prof[].
 #if defined(NTE_PROFILE)
 static __device__ unsigned long long g_prof[64]; // (one per translation unit: the kernels are compiled per configuration)
+// events that took more than 2^22 ticks, for the question "which events is a launch waiting for": [0] = entries written,
+// then {start position in the batch, begin tick, end tick, positions the run covered} per event (k_machine's wrapper)
+constexpr unsigned NTE_EVLOG_CAP = 8192;
+static __device__ unsigned long long g_evlog[4 + 4 * NTE_EVLOG_CAP];
+// filter bytes gathered by the events that start in each 4 Mbase stretch of the batch (k_machine's wrapper): where the work is
+constexpr unsigned NTE_REGION_SHIFT = 22, NTE_REGIONS = 4096;
+static __device__ unsigned long long g_region[NTE_REGIONS];
 #endif
 #if defined(NTE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define NTE_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_t0 = prof_t, prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }

@@ -85,7 +85,9 @@ int assess_tile();
 	void launch_k_machine_thread_cfg##C(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);     \
 	void launch_k_machine_wave_cfg##C(unsigned blocks, size_t dyn_lds, hipStream_t stream, const MachineArgs& a);       \
 	void machine_wave_profile_cfg##C(unsigned long long out[64]);                                                       \
-	unsigned long long machine_thread_gathers_cfg##C();
+	unsigned long long machine_thread_gathers_cfg##C();                                                                 \
+	unsigned machine_thread_evlog_cfg##C(unsigned long long* out, unsigned cap);                                         \
+	unsigned machine_wave_evlog_cfg##C(unsigned long long* out, unsigned cap);
 NTE_MACHINE_CFGS(NTE_DECL_MACHINE)
 #undef NTE_DECL_MACHINE
 
@@ -132,6 +134,17 @@ machine_thread_gathers()
 	NTE_MACHINE_CFGS(NTE_SUM)
 #undef NTE_SUM
 	return v;
+}
+
+// the long events of the launches since the last call (profile build), of the thread- / wavefront-per-event kernels
+inline unsigned
+machine_evlog(bool wave, unsigned long long* out, unsigned cap)
+{
+	unsigned n = 0;
+#define NTE_SUM(C) n += wave ? machine_wave_evlog_cfg##C(out + 4 * n, cap - n) : machine_thread_evlog_cfg##C(out + 4 * n, cap - n);
+	NTE_MACHINE_CFGS(NTE_SUM)
+#undef NTE_SUM
+	return n;
 }
 
 inline void

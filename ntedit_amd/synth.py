@@ -126,6 +126,7 @@ class GenomeStructure:
         self.short_family = truth_codes(300, g, device)
         self.long_family = truth_codes(6000, g, device)
         self.bases = dict(simple=0, sat=0, dispersed=0, segdup=0, novel=0)
+        self.features = []  # (contig, start, length, class) of the arrays / duplications / novel stretches (diagnosis)
 
     def _spans(self, rng, L, share, lo, hi):
         """feature lengths of one class for a contig of L bases"""
@@ -171,18 +172,21 @@ class GenomeStructure:
             at = int(rng.integers(0, L - n + 1))
             t[at:at + n] = _diverge(arr, float(rng.uniform(0.01, 0.02)), gen)
             self.bases["simple"] += n
+            self.features.append((index, at, n, "simple%d" % period))
         for n in self._spans(rng, L, self.frac["sat"], 10_000, 5_000_000):
             m = self.monomers[int(rng.integers(0, len(self.monomers)))]
             arr = m.repeat((n + 170) // 171)[:n]
             at = int(rng.integers(0, L - n + 1))
             t[at:at + n] = _diverge(arr, float(rng.uniform(0.02, 0.05)), gen)
             self.bases["sat"] += n
+            self.features.append((index, at, n, "sat"))
         for n in self._spans(rng, L, self.frac["segdup"], 10_000, 200_000):
             src = int(rng.integers(0, L - n + 1))
             dst = int(rng.integers(0, L - n + 1))
             piece = _diverge(t[src:src + n].clone(), float(rng.uniform(0.01, 0.02)), gen)
             t[dst:dst + n] = _revcomp(piece) if rng.random() < 0.5 else piece
             self.bases["segdup"] += n
+            self.features.append((index, dst, n, "segdup"))
         spans = self._spans(rng, L, self.frac["novel"], 2_000, 50_000)
         if not spans:
             return None
@@ -191,6 +195,7 @@ class GenomeStructure:
             at = int(rng.integers(0, L - n + 1))
             novel[at:at + n] = True
             self.bases["novel"] += n
+            self.features.append((index, at, n, "novel"))
         return novel
 
 

@@ -531,6 +531,46 @@ def make_tail_case(tmp, k=31):
     return {"draft": os.path.join(tmp, "draft.fa"), "bf": os.path.join(tmp, "t.bf"), "rep": None}
 
 
+def make_contig_end_case(tmp, k=25, seed=11):
+    """Errors planted at every distance 0 .. 2k + 14 from a contig's end (substitutions, 1-3 base deletions and insertions,
+    pairs of errors a few bases apart): the positions in front of a contig's end are where the character window of a
+    failing position is cut short (nte_machine_sweeps.inc: win_rolls) or not available at all (the last k)."""
+    os.makedirs(tmp, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    truth = random_genome(rng, 300000)
+    write_fasta(os.path.join(tmp, "truth.fa"), [(b"t", truth)])
+    mkbf([os.path.join(tmp, "truth.fa")], os.path.join(tmp, "t.bf"), k=k, hashes=3, nbytes=1 << 20)
+    draft = []
+    n = 0
+    for dist in range(0, 2 * k + 15):
+        for kind in range(8):
+            L = int(rng.integers(4 * k, 8 * k))
+            st = int(rng.integers(0, len(truth) - L))
+            d = bytearray(truth[st:st + L])
+            at = L - 1 - dist
+
+            def sub(q):
+                d[q] = b"ACGT"[(b"ACGT".index(d[q]) + 1 + int(rng.integers(0, 3))) % 4]
+            if kind == 0:
+                sub(at)
+            elif kind in (1, 2, 3):
+                del d[at:at + kind]            # the draft lacks 1-3 bases: an insertion repairs it
+            elif kind in (4, 5):
+                d[at:at] = random_genome(rng, kind - 3)  # 1-2 extra bases: a deletion repairs it
+            elif kind == 6:
+                sub(at)
+                if at >= 7:
+                    sub(at - 7)
+            else:
+                sub(at)
+                if at >= 3:
+                    del d[at - 3:at - 2]
+            draft.append((b"end%d" % n, bytes(d)))
+            n += 1
+    write_fasta(os.path.join(tmp, "draft.fa"), draft, width=0)
+    return {"draft": os.path.join(tmp, "draft.fa"), "bf": os.path.join(tmp, "t.bf"), "rep": None}
+
+
 def make_many_case(tmp, n_contigs=3000, mean_len=500, seed=7):
     """Fragmented-assembly shape: thousands of short contigs cut from one truth genome, with errors, some
     lowercase stretches and Ns (several renderer work units, events in most contigs)."""

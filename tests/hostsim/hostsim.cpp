@@ -287,6 +287,9 @@ hostsim_polish(
 		if (const char* it = getenv("HOSTSIM_DEFER_RUN")) {
 			pe.defer_run = (u32)atoi(it);
 		}
+		if (const char* it = getenv("HOSTSIM_DEFER_FAIL")) {
+			pe.defer_fail = (u32)atoi(it);
+		}
 		EventEnv env;
 		env.seq = (const u8*)bases + offsets[ci];
 		env.batch_end = (const u8*)bases + n;

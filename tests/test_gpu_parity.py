@@ -741,6 +741,30 @@ def test_make_genome_bf_cli(tmp_path, oracle_build):
     assert subprocess.run([tool, "--genome", str(tmp_path / "g1.fa")], capture_output=True).returncode == 1
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(max_deletions=10, max_insertions=5), dict(mode=1), dict(snv=1), dict(k=40),
+                                dict(jump=1, max_deletions=8)])
+def test_errors_in_front_of_contig_ends_gpu(tmp_path, oracle_build, kw):
+    """the GPU twin of test_hostsim_parity.test_errors_in_front_of_contig_ends: errors at every distance from a contig's
+    end, where the character window is cut short (round 6; until then those positions went through the general
+    rope-walking paths, a sweep of 341 candidates probed one k-mer after the other)"""
+    kw = dict(kw)
+    k = kw.pop("k", 25)
+    case = H.make_contig_end_case(str(tmp_path), k=k)
+    hp = H.default_params(min_contig_len=0, **kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"))
+    for general in (False, True):
+        pol = _fresh(general=general)
+        try:
+            _load_filters(pol, case)
+            pol.set_params(_hip_params(min_contig_len=0, **kw))
+            pol.polish_records(H.read_fasta(case["draft"]), str(tmp_path / "g"))
+        finally:
+            pol.close()
+        for suf in ("_changes.tsv", "_edited.fa"):
+            assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("g" + suf)), shallow=False), suf
+        assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "g_variants.vcf"))
+
+
 def test_parked_events_resolve_quickly(tmp_path, oracle_build):
     """Nearly every event parked by a tiny budget on a draft where hardly a k-mer is in the filter (the regime of fuzz seed
     42424200091: k=128, 1.7 % errors, budget 8; a third of its length here).  What the serial order applies there is ONE

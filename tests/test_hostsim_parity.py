@@ -136,6 +136,33 @@ def test_many_short_contigs(tmp_path, oracle_build, monkeypatch, unit, threads, 
     assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))
 
 
+CONTIG_END_PARAMS = [dict(), dict(max_deletions=10, max_insertions=5), dict(mode=1), dict(mode=2, max_insertions=2),
+                     dict(max_deletions=0), dict(max_insertions=0, max_deletions=3), dict(snv=1), dict(mask=1),
+                     dict(k=40), dict(jump=1, max_deletions=8)]
+
+
+@pytest.mark.parametrize("two_pass", [False, True])
+@pytest.mark.parametrize("kw", CONTIG_END_PARAMS)
+def test_errors_in_front_of_contig_ends(tmp_path, oracle_build, monkeypatch, kw, two_pass):
+    """errors at every distance from a contig's end (helpers.make_contig_end_case): the window of a failing position is cut
+    where the contig ends, the walks behind a deletion with it, the last k positions are given up -- as the reference's
+    loops do when roll() fails (ntedit.cpp:1216-1247, 1494-1519, 1826-1858)"""
+    kw = dict(kw)
+    k = kw.pop("k", 25)
+    if two_pass:
+        monkeypatch.setenv("HOSTSIM_TWO_PASS", "1")
+    else:
+        monkeypatch.delenv("HOSTSIM_TWO_PASS", raising=False)
+    case = H.make_contig_end_case(str(tmp_path), k=k)
+    hp = H.default_params(min_contig_len=0, **kw)
+    H.run_oracle(case["draft"], case["bf"], hp, str(tmp_path / "o"))
+    rc, nev, nap = H.run_hostsim(H.read_fasta(case["draft"]), H.load_bf(case["bf"]), hp, str(tmp_path / "h"))
+    assert rc == 0 and nap > 20
+    for suf in ("_changes.tsv", "_edited.fa"):
+        assert filecmp.cmp(str(tmp_path / ("o" + suf)), str(tmp_path / ("h" + suf)), shallow=False), suf
+    assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "h_variants.vcf"))
+
+
 @pytest.mark.parametrize("ci", [0, 5, 9, 10, 22, 28, 31])
 def test_edit_records_rebuild_the_tsv(tmp_path, ci, oracle_build):
     """the POD edit records of the C ABI (ntedit_hip_result_edits; here straight from the product's renderer on

@@ -400,6 +400,13 @@ void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
  * NTEDIT_HIP_NO_BIND (see ntedit_hip_bind_near_device). */
 int ntedit_hip_set_tuning(ntedit_hip_ctx* ctx, const char* key, uint64_t value);
 
+/* The reference's candidate tables -- num_tries, polish_bases_array / snv_bases_array, multi_possible_bases (ntedit.cpp:172,
+ * 176-199, 203-348) -- as the device code holds them (one GPU thread runs the machine's own candidate_bases /
+ * insertion_candidate), as text: "num_tries 0 1 5 21 85 341", "polish A TCG", ..., "snv N ATCG", "multi A A AA AC ...".
+ * tests/ compare its SHA-256 per section with the hashes of the same text extracted from the reference's source
+ * (tests/golden/reference_tables.json, tests/tools/reference_tables.py).  *len = bytes needed (without the 0). */
+int ntedit_hip_device_tables(ntedit_hip_ctx* ctx, char* out, uint64_t cap, uint64_t* len);
+
 /* Identifies what the library's kernels were built from (a hash of the device-side sources, set by the Makefile):
  * bench.py stamps the counter records it keeps under profiles/ with it and quotes them only for the same build.
  * No counterpart in the reference. */

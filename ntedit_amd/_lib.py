@@ -106,7 +106,7 @@ EXPORTS = [
     "ntedit_hip_annot_load", "ntedit_hip_annot_free", "ntedit_hip_write_vcf_header", "ntedit_hip_write_outputs_vcf",
     "ntedit_hip_set_host_threads", "ntedit_hip_filter_occupancy",
     "ntedit_hip_write_outputs_ex", "ntedit_hip_result_cover_ends", "ntedit_hip_result_edits",
-    "ntedit_hip_host_alloc", "ntedit_hip_host_free", "ntedit_hip_bind_near_device", "ntedit_hip_set_tuning", "ntedit_hip_build_id", "ntedit_hip_packed_size", "ntedit_hip_pack_bases",
+    "ntedit_hip_host_alloc", "ntedit_hip_host_free", "ntedit_hip_bind_near_device", "ntedit_hip_set_tuning", "ntedit_hip_build_id", "ntedit_hip_device_tables", "ntedit_hip_packed_size", "ntedit_hip_pack_bases",
     "ntedit_hip_fasta_load", "ntedit_hip_fasta_count", "ntedit_hip_fasta_blob", "ntedit_hip_fasta_record",
     "ntedit_hip_fasta_free", "ntedit_hip_result_cuts_ok", "ntedit_hip_reserve",
 ]

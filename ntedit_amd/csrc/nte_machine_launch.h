@@ -123,6 +123,10 @@ launch_k_machine_wave(unsigned blocks, size_t dyn_lds, hipStream_t stream, const
 	}
 }
 
+// the device code's candidate tables, raw (nte_machine_thread.hip: k_tables; 30 * 8 + 4 * 341 * 8 bytes)
+constexpr size_t TABLES_RAW_BYTES = 30 * 8 + 4 * 341 * 8;
+void launch_k_tables(hipStream_t stream, u8* out);
+
 // lanes per event in that kernel (a 256-thread block runs 256 / group events at a time)
 int machine_wave_group();
 

@@ -32,6 +32,47 @@ NTE_CAT(machine_thread_gathers_cfg, NTE_CFG)()
 	return v;
 }
 
+#if NTE_CFG == 0
+// The candidate tables of ntedit.cpp:176-348 as the DEVICE code holds them (MachineT::candidate_bases /
+// insertion_candidate run by one GPU thread), raw: out[0 .. 30 * 8): per {snv, letter of "ATCGRYSWKMBDHVN"} the
+// count and the candidates; then per index base of "ACGT" 341 entries of 8 bytes {length, characters}.
+// ntedit_hip_device_tables() turns them into the text tests/tools/reference_tables.py hashes.
+__global__ void
+k_tables(u8* out)
+{
+	const char* letters = "ATCGRYSWKMBDHVN";
+	for (int snv = 0; snv < 2; snv++) {
+		for (int l = 0; l < 15; l++) {
+			u8 cand[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+			const u32 nc = MachineT<0>::candidate_bases((u8)letters[l], snv != 0, cand);
+			u8* o = out + (snv * 15 + l) * 8;
+			o[0] = (u8)nc;
+			for (int q = 0; q < 7; q++) {
+				o[1 + q] = cand[q];
+			}
+		}
+	}
+	const char* acgt = "ACGT";
+	for (int b = 0; b < 4; b++) {
+		for (u32 i = 0; i < 341; i++) {
+			u8 ins[INDEL_BYTES] = { 0 };
+			const u32 m = MachineT<0>::insertion_candidate((u8)acgt[b], i, ins);
+			u8* o = out + 30 * 8 + ((size_t)b * 341 + i) * 8;
+			o[0] = (u8)m;
+			for (u32 q = 0; q < 7; q++) {
+				o[1 + q] = q < m ? ins[q] : 0;
+			}
+		}
+	}
+}
+
+void
+launch_k_tables(hipStream_t stream, u8* out)
+{
+	hipLaunchKernelGGL(k_tables, dim3(1), dim3(1), 0, stream, out);
+}
+#endif
+
 // events of more than 2^22 ticks logged by a -DNTE_PROFILE build (nte_machine.h: g_evlog); reading resets the log.
 // Returns the entries written to out[4 * cap] ({position, begin tick, end tick, covered | flags << 32}).
 unsigned

@@ -332,6 +332,13 @@ class Polisher:
         self._check(self._lib.ntedit_hip_reserve(self._h, int(max_batch_bytes), int(max_contigs), int(events_hint),
                                                  int(on_device)), "reserve")
 
+    def device_tables(self):
+        """ntedit_hip_device_tables: the reference's candidate tables as the device code holds them, as text"""
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = ctypes.c_uint64()
+        self._check(self._lib.ntedit_hip_device_tables(self._h, buf, ctypes.c_uint64(len(buf)), ctypes.byref(n)), "device_tables")
+        return buf.raw[:n.value].decode()
+
     def set_tuning(self, key, value):
         """Test / tuning knobs (include/ntedit_hip.h: none of them can change a result)."""
         self._check(self._lib.ntedit_hip_set_tuning(self._h, key.encode(), int(value)), "set_tuning")

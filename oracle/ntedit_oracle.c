@@ -2708,3 +2708,49 @@ ora_polish_batch_flat_mt_files(
 	}
 	return j.total;
 }
+
+/* ---- the tables of ntedit.cpp:172-348 as this restatement holds them, in the canonical text form of
+ * tests/tools/reference_tables.py ("num_tries ...", "polish X cands", "snv X cands", "multi X cand cand ..."): the CPU tier
+ * compares it with the text extracted from the reference's source, where that is present.  Returns the length written
+ * (without the terminating 0), or -1 when cap is too small. */
+long
+ora_tables_dump(char* out, size_t cap)
+{
+	size_t n = 0;
+#define ORA_PUT(...)                                                   \
+	do {                                                               \
+		int w_ = snprintf(out + n, n < cap ? cap - n : 0, __VA_ARGS__); \
+		if (w_ < 0 || n + (size_t)w_ >= cap) {                         \
+			return -1;                                                 \
+		}                                                              \
+		n += (size_t)w_;                                               \
+	} while (0)
+	ORA_PUT("num_tries");
+	for (int i = 0; i < 6; i++) {
+		ORA_PUT(" %u", num_tries[i]);
+	}
+	ORA_PUT("\n");
+	static const char letters[] = "ATCGRYSWKMBDHVN";
+	for (int snv = 0; snv < 2; snv++) {
+		for (const char* c = letters; *c; c++) {
+			unsigned char cand[8];
+			unsigned nc = candidate_bases(snv, (unsigned char)*c, cand);
+			ORA_PUT("%s %c ", snv ? "snv" : "polish", *c);
+			for (unsigned q = 0; q < nc; q++) {
+				ORA_PUT("%c", cand[q]);
+			}
+			ORA_PUT("\n");
+		}
+	}
+	for (const char* c = "ACGT"; *c; c++) {
+		ORA_PUT("multi %c", *c);
+		for (unsigned i = 0; i < num_tries[5]; i++) {
+			char ins[8];
+			insertion_candidate((unsigned char)*c, i, ins);
+			ORA_PUT(" %s", ins);
+		}
+		ORA_PUT("\n");
+	}
+#undef ORA_PUT
+	return (long)n;
+}

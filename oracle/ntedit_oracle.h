@@ -229,4 +229,7 @@ extern __thread ora_counters ora_ctr;
 #ifdef __cplusplus
 }
 #endif
+/* the tables of ntedit.cpp:172-348 as text (tests/tools/reference_tables.py); length written or -1 */
+long ora_tables_dump(char* out, size_t cap);
+
 #endif

@@ -648,3 +648,62 @@ hostsim_filter_slots(unsigned long long slots, const unsigned long long* hv, uns
 		out[i] = nte::filter_slot(f, hv[i]);
 	}
 }
+
+// The tables of ntedit.cpp:172-348 as the PRODUCT's sources hold them -- MachineT::candidate_bases / insertion_candidate
+// (nte_machine_position.inc / _rope.inc, the very functions the kernels run) and params.cpp's num_tries, read through
+// DevParams::ins_tries -- in the canonical text form of tests/tools/reference_tables.py.  Length written or -1.
+extern "C" long
+hostsim_tables_dump(char* out, size_t cap)
+{
+	size_t n = 0;
+	auto put = [&](const char* fmt, auto... a) -> bool {
+		int w = snprintf(out + n, n < cap ? cap - n : 0, fmt, a...);
+		if (w < 0 || n + (size_t)w >= cap) {
+			return false;
+		}
+		n += (size_t)w;
+		return true;
+	};
+	if (!put("num_tries")) {
+		return -1;
+	}
+	for (uint32_t i = 0; i <= 5; i++) {
+		ntedit_hip_params hp;
+		nte_host::params_default(&hp);
+		hp.max_insertions = i;
+		hp.max_deletions = i < 2 ? i : hp.max_deletions;
+		DevParams d;
+		if (nte_host::make_dev_params(hp, 25, 3, false, &d) != 0 || !put(" %u", d.ins_tries)) {
+			return -1;
+		}
+	}
+	put("\n");
+	for (int snv = 0; snv < 2; snv++) {
+		for (const char* c = "ATCGRYSWKMBDHVN"; *c; c++) {
+			u8 cand[8];
+			const u32 nc = MachineT<0>::candidate_bases((u8)*c, snv != 0, cand);
+			if (!put("%s %c ", snv ? "snv" : "polish", *c)) {
+				return -1;
+			}
+			for (u32 q = 0; q < nc; q++) {
+				put("%c", cand[q]);
+			}
+			put("\n");
+		}
+	}
+	for (const char* c = "ACGT"; *c; c++) {
+		if (!put("multi %c", *c)) {
+			return -1;
+		}
+		for (u32 i = 0; i < 341; i++) {
+			u8 ins[INDEL_BYTES + 1];
+			const u32 m = MachineT<0>::insertion_candidate((u8)*c, i, ins);
+			ins[m] = 0;
+			if (!put(" %s", (const char*)ins)) {
+				return -1;
+			}
+		}
+		put("\n");
+	}
+	return (long)n;
+}

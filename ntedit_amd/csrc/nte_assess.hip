@@ -10,8 +10,9 @@
 // survive.  The event machine starts, goes on and stops by the run map (a cleared position is to it what a present
 // k-mer is) and still reads the absent bitmap where step 2 asks for it, so nothing changes but the work.
 // The tests are Machine::assess_lane<GATE> itself (nte_machine.h) on a character window shared by the workgroup;
-// positions the window cannot serve (a non-accepted character within k + max_del + 1 bases behind the k-mer, the
-// end of a contig, bytes the 4-bit codes cannot express) keep their bit.
+// positions the window cannot serve (a non-accepted character or the end of the contig within k bases behind the
+// k-mer) are asked the gate's first question only, which reads the k-mer's own codes; where a tile holds bytes the
+// 4-bit codes cannot express they keep their bit.
 #include "nte_machine_launch.h"
 
 #include <hip/hip_runtime.h>
@@ -39,8 +40,9 @@ k_assess(AssessArgs a)
 		s_tab[threadIdx.x] = a.tabs[threadIdx.x];
 	}
 	const u32 k = a.p.k;
-	const u32 K = k + a.p.max_deletions + 1; // Machine::win_len_in()
-	const u32 need = k + K;                  // accepted codes a position's window holds
+	// accepted codes the gate reads at a position: its k-mer and the k rolls of step 2 / the substitution walks (the gate
+	// never sweeps; round 6: until then the whole window of a failing position, k + max_del + 1 rolls, was asked for)
+	const u32 need = 2 * k;
 	const u32 span = ASSESS_TILE + need;     // codes a tile's lanes read
 	EventEnv env;
 	env.seq = a.seq;
@@ -114,10 +116,15 @@ k_assess(AssessArgs a)
 			for (u32 j = 0; j < (u32)ASSESS_L; j++) {
 				if ((abits >> j) & 1) {
 					bool kp = true;
+					m.win_off = x0 + j;
 					if (good >= need) {
-						m.win_off = x0 + j;
 						m.hs = hs;
 						kp = m.assess_gate(p0 + j, a.seq[p0 + j + k - 1]);
+					} else {
+						// no full window (a contig ends, a non-accepted character is ahead): the k-mer's own codes -- accepted,
+						// or the bit would not be set -- answer the gate's first question
+						m.hs = m.seed_from_window();
+						kp = m.assess_gate_kmer_only();
 					}
 					keep |= kp ? 1u << j : 0u;
 				}

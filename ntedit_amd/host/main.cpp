@@ -648,7 +648,9 @@ main(int argc, char** argv)
 		ntedit_hip_set_host_threads(nthreads); // -t: contigs rendered concurrently
 	}
 	unsigned long long n_contigs = 0, total_bases = 0;
-	double ms_gpu = 0, ms_screen = 0, s_call = 0, s_write = 0, s_read = 0;
+	double ms_gpu = 0, ms_screen = 0, ms_machine = 0, s_call = 0, s_write = 0, s_read = 0;
+	unsigned n_batches_binned = 0, n_batches_direct = 0, n_chunks_direct = 0;
+	unsigned long long n_ovf_records = 0;
 	ntedit_hip_stats tot;
 	memset(&tot, 0, sizeof tot);
 
@@ -869,6 +871,13 @@ main(int argc, char** argv)
 			ntedit_hip_result_stats(w->res, &st);
 			ms_gpu += st.ms_total;
 			ms_screen += st.ms_screen;
+			// (which screening kernels ran: batches on the partitioned pipeline / on the direct kernel, record chunks the direct
+			// kernel had to screen again, overflow-list entries)
+			n_batches_binned += st.screen_binned ? 1 : 0;
+			n_batches_direct += st.screen_binned ? 0 : 1;
+			n_chunks_direct += st.screen_chunks_direct;
+			n_ovf_records += st.screen_overflow_records;
+			ms_machine += st.ms_machine;
 			tot.events += st.events;
 			tot.events_applied += st.events_applied;
 			tot.absent_kmers += st.absent_kmers;
@@ -918,10 +927,11 @@ main(int argc, char** argv)
 	printf("---------- process complete                         : %s", ctime(&rawtime));
 	if (report) {
 		double s = std::chrono::duration<double>(t1 - t0).count();
-		printf("{\"bases\": %llu, \"seconds\": %.6f, \"open_outputs_s\": %.3f, \"index_s\": %.3f, \"read_s\": %.3f, \"polish_call_s\": %.3f, \"write_s\": %.3f, \"gpu_ms\": %.3f, \"screen_ms\": %.3f, \"events\": %llu, "
+		printf("{\"bases\": %llu, \"seconds\": %.6f, \"open_outputs_s\": %.3f, \"index_s\": %.3f, \"read_s\": %.3f, \"polish_call_s\": %.3f, \"write_s\": %.3f, \"gpu_ms\": %.3f, \"screen_ms\": %.3f, \"machine_ms\": %.3f, "
+		       "\"screening\": {\"batches_partitioned\": %u, \"batches_direct_kernel\": %u, \"record_chunks_rescreened_direct\": %u, \"overflow_records\": %llu}, \"events\": %llu, "
 		       "\"events_applied\": %llu, \"absent_kmers\": %llu, \"substitutions\": %llu, \"insertions\": %llu, "
 		       "\"deletions\": %llu}\n",
-		       total_bases, s, s_before_index, s_index, s_read, s_call, s_write, ms_gpu, ms_screen, (unsigned long long)tot.events,
+		       total_bases, s, s_before_index, s_index, s_read, s_call, s_write, ms_gpu, ms_screen, ms_machine, n_batches_binned, n_batches_direct, n_chunks_direct, (unsigned long long)n_ovf_records, (unsigned long long)tot.events,
 		       (unsigned long long)tot.events_applied, (unsigned long long)tot.absent_kmers,
 		       (unsigned long long)tot.substitutions, (unsigned long long)tot.insertions,
 		       (unsigned long long)tot.deletions);

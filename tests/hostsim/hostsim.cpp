@@ -108,18 +108,26 @@ sim_assess(const u8* seq, u64 n, const Filter& f, const Filter& fr, const DevPar
 		if (!bit_absent(bitmap, g)) {
 			continue;
 		}
-		bool clear = g + p.k + K <= n;
-		for (u32 i = 0; clear && i < p.k + K; i++) {
+		bool clear = g + 2 * p.k <= n; // (the k-mer and the k rolls the gate makes; k_assess: `need`)
+		for (u32 i = 0; clear && i < 2 * p.k; i++) {
 			const u8 code = char_code(seq[g + i]);
 			clear = code != CODE_BAD;
 			win[i] = code;
 		}
-		if (!clear) {
-			continue; // (a non-accepted character within reach: the bit stays)
-		}
 		MachineT<0> m(env);
 		m.win_off = 0;
 		m.win_ok = true;
+		if (!clear) {
+			// (a non-accepted character or the end of the batch within reach: the k-mer's own codes only)
+			for (u32 i = 0; i < p.k; i++) {
+				win[i] = char_code(seq[g + i]);
+			}
+			m.hs = m.seed_from_window();
+			if (!m.assess_gate_kmer_only()) {
+				runmap[g >> 6] &= ~(1ULL << (g & 63));
+			}
+			continue;
+		}
 		m.hs = m.seed_from_window();
 		if (!m.assess_gate(g, seq[g + p.k - 1])) {
 			runmap[g >> 6] &= ~(1ULL << (g & 63));

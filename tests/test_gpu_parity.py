@@ -5,6 +5,7 @@ byte-identical.  Nothing here reads /root/reference."""
 import ctypes
 import filecmp
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -639,6 +640,27 @@ def test_genome_like_3gbp_every_contig(tmp_path, oracle_build, capsys):
         assert st.substitutions > 0.5e-3 * job.n_bases and st.insertions > 0 and st.deletions > 0
     finally:
         pol.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_genome_like_cases_at_real_run_sizes(tmp_path, oracle_build, capsys, seed):
+    """three draws of tests/tools/fuzz_genome_like.py (72-160 Mbases, repeat flavours at random shares, the partitioned
+    screening at its real run sizes -- no bin_cap_percent --, one draw forced to half a draft of simple sequence, where a record
+    chunk's overflow list runs out and the direct kernel takes the chunk): every contig identical to the oracle's"""
+    sys.path.insert(0, os.path.join(H.ROOT, "tests", "tools"))
+    import fuzz_genome_like as F
+    rng = np.random.default_rng(seed)
+    c = F.draw(rng)
+    if seed == 13:
+        c["fractions"]["simple"] = 0.5
+        c["filter_bytes"] = 1 << 30
+        c["bases"] = 96e6
+    ok, info = F.run_case(c, str(tmp_path))
+    with capsys.disabled():
+        print("\n[genome-like %d] %s: %s" % (seed, c, info), flush=True)
+    assert ok
+    if seed == 13:
+        assert "screening partitioned" in info
 
 
 def test_config2_250mbp_every_contig(tmp_path, oracle_build, capsys):

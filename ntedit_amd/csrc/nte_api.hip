@@ -123,6 +123,8 @@ struct ntedit_hip_ctx
 		u32 lanes = ~0u;         // DevParams::lanes (~0: default)
 		u32 defer_run = ~0u;     // DevParams::defer_run (~0: default)
 		u32 defer_fail = ~0u;    // DevParams::defer_fail (~0: default)
+		u32 h2d_fixed_schedule = 0; // a batch arriving in pieces: round 3's chunk schedule (1, 3, 8 pieces, the rest) instead of chunks by arrival
+		u32 snv_wave = 0;        // -s 1 with the run map: the events go to the wavefront-per-event launch (experiment)
 		u32 no_rounds = 0, no_early_copy = 0;
 		u32 force_rounds = 0;     // event rounds whatever the number of events (tests: small inputs)
 		u32 bin_scatter = 0;      // partition kernel: 0 barrier-phased (k_wc_scatter_b), 1 barrier-free (k_wc_scatter)

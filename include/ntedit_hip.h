@@ -373,6 +373,12 @@ int ntedit_hip_gather_bench(ntedit_hip_ctx* ctx, uint64_t nbytes, uint64_t n_pro
  * half-way (NTEDIT_E_IO; kseq would stop silently).  threads 0 = default. */
 typedef struct ntedit_hip_fasta ntedit_hip_fasta;
 int ntedit_hip_fasta_load(const char* path, uint64_t min_len, unsigned threads, ntedit_hip_fasta** out, char* err, size_t errcap);
+/* The same records WITHOUT their bases: the file is mapped and indexed (headers, lengths), sequences are read on demand with
+ * ntedit_hip_fasta_read -- what a rank of a multi-GPU run needs to plan the partition and then read its own share
+ * (python -m ntedit_amd.run).  ntedit_hip_fasta_record() then reports offset = ~0 and ntedit_hip_fasta_blob() nothing.  Inputs
+ * the mapped reader does not take (single-stream gzip, FASTQ, ...) are loaded whole; the calls behave the same. */
+int ntedit_hip_fasta_open(const char* path, uint64_t min_len, unsigned threads, ntedit_hip_fasta** out, char* err, size_t errcap);
+int ntedit_hip_fasta_read(const ntedit_hip_fasta* f, uint64_t i, uint64_t start, uint64_t n, char* dst);
 uint64_t ntedit_hip_fasta_count(const ntedit_hip_fasta* f);
 const char* ntedit_hip_fasta_blob(const ntedit_hip_fasta* f, uint64_t* nbytes);
 int ntedit_hip_fasta_record(const ntedit_hip_fasta* f, uint64_t i, const char** header, uint64_t* header_len, uint64_t* offset, uint64_t* len);

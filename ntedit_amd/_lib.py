@@ -107,7 +107,7 @@ EXPORTS = [
     "ntedit_hip_set_host_threads", "ntedit_hip_filter_occupancy",
     "ntedit_hip_write_outputs_ex", "ntedit_hip_result_cover_ends", "ntedit_hip_result_edits",
     "ntedit_hip_host_alloc", "ntedit_hip_host_free", "ntedit_hip_bind_near_device", "ntedit_hip_set_tuning", "ntedit_hip_build_id", "ntedit_hip_device_tables", "ntedit_hip_packed_size", "ntedit_hip_pack_bases",
-    "ntedit_hip_fasta_load", "ntedit_hip_fasta_count", "ntedit_hip_fasta_blob", "ntedit_hip_fasta_record",
+    "ntedit_hip_fasta_load", "ntedit_hip_fasta_open", "ntedit_hip_fasta_read", "ntedit_hip_fasta_count", "ntedit_hip_fasta_blob", "ntedit_hip_fasta_record",
     "ntedit_hip_fasta_free", "ntedit_hip_result_cuts_ok", "ntedit_hip_reserve",
 ]
 
@@ -187,6 +187,8 @@ def load():
     lib.ntedit_hip_result_cuts_ok.argtypes = [vp, u32, vp, vp, vp]
     lib.ntedit_hip_fasta_load.argtypes = [ctypes.c_char_p, u64, ctypes.c_uint, ctypes.POINTER(vp), ctypes.c_char_p,
                                           ctypes.c_size_t]
+    lib.ntedit_hip_fasta_open.argtypes = lib.ntedit_hip_fasta_load.argtypes
+    lib.ntedit_hip_fasta_read.argtypes = [vp, u64, u64, u64, vp]
     lib.ntedit_hip_fasta_count.argtypes = [vp]
     lib.ntedit_hip_fasta_count.restype = u64
     lib.ntedit_hip_fasta_blob.argtypes = [vp, ctypes.POINTER(u64)]

@@ -26,6 +26,11 @@ struct ntedit_hip_fasta
 	std::vector<uint64_t> offs;
 	std::vector<uint64_t> lens;
 	std::string blob; // every sequence followed by '\n': the batch layout of ntedit_hip_polish_batch
+	// ntedit_hip_fasta_open: the mapped file and its record index instead of a blob (offs[] = ~0); sequences are read
+	// on demand (ntedit_hip_fasta_read)
+	nte_host::FastaMap* map = nullptr;
+	std::vector<size_t> map_idx; // record i of this handle = record map_idx[i] of the file
+	~ntedit_hip_fasta() { delete map; }
 };
 
 static void
@@ -37,6 +42,68 @@ set_err(char* err, size_t cap, const std::string& text)
 }
 
 extern "C" {
+
+// The draft's INDEX without its bases: the file is mapped, its records are found and measured by `threads` threads, and
+// nothing is copied -- a rank of a multi-GPU run plans the partition from the lengths and then reads its own pieces
+// (and the 64 KB windows its cuts are looked for in) with ntedit_hip_fasta_read.  Inputs the mapped reader does not
+// take (single-stream gzip, FASTQ, CR line ends, ...) are loaded whole, as ntedit_hip_fasta_load does: same calls,
+// same results, the bases then come out of memory.
+int
+ntedit_hip_fasta_open(const char* path, uint64_t min_len, unsigned threads, ntedit_hip_fasta** out, char* err, size_t errcap)
+{
+	if (!path || !out) {
+		set_err(err, errcap, "fasta_open: bad argument");
+		return NTEDIT_E_ARG;
+	}
+	*out = nullptr;
+	unsigned t = threads;
+	if (t == 0) {
+		t = std::thread::hardware_concurrency();
+		t = t > 16 ? 16 : (t < 1 ? 1 : t);
+	}
+	try {
+		nte_host::FastaMap* m = new nte_host::FastaMap(path, t, t > 64 ? 64 : t);
+		if (m->ok()) {
+			ntedit_hip_fasta* f = new ntedit_hip_fasta();
+			f->map = m;
+			const size_t N = m->records();
+			m->measure(0, N);
+			for (size_t i = 0; i < N; i++) {
+				if (m->length(i) >= min_len) {
+					f->map_idx.push_back(i);
+					f->offs.push_back(~0ULL);
+					f->lens.push_back(m->length(i));
+					f->headers.push_back(m->header(i));
+				}
+			}
+			*out = f;
+			return 0;
+		}
+		delete m;
+	} catch (...) {
+		set_err(err, errcap, std::string("`") + path + "': failure while indexing the draft");
+		return NTEDIT_E_IO;
+	}
+	return ntedit_hip_fasta_load(path, min_len, threads, out, err, errcap);
+}
+
+// bases [start, start + n) of record i of a handle of ntedit_hip_fasta_open / _load to dst
+int
+ntedit_hip_fasta_read(const ntedit_hip_fasta* f, uint64_t i, uint64_t start, uint64_t n, char* dst)
+{
+	if (!f || i >= f->lens.size() || start > f->lens[i] || n > f->lens[i] - start || (n && !dst)) {
+		return NTEDIT_E_ARG;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	if (f->map) {
+		f->map->copy_range(f->map_idx[i], start, n, dst);
+	} else {
+		memcpy(dst, f->blob.data() + f->offs[i] + start, (size_t)n);
+	}
+	return 0;
+}
 
 int
 ntedit_hip_fasta_load(const char* path, uint64_t min_len, unsigned threads, ntedit_hip_fasta** out, char* err, size_t errcap)

@@ -307,4 +307,32 @@ FastaMap::copy(const size_t* idx, char* const* dst, size_t n) const
 	});
 }
 
+void
+FastaMap::copy_range(size_t i, uint64_t start, uint64_t n, char* dst) const
+{
+	const Rec& r = recs_[i];
+	const char* p = data_ + r.seq;
+	const char* e = data_ + r.end;
+	uint64_t skip = start;
+	while (p < e && n) {
+		const char* q = (const char*)memchr(p, '\n', (size_t)(e - p));
+		uint64_t len = q ? (uint64_t)(q - p) : (uint64_t)(e - p);
+		const char* line = p;
+		p += len + 1;
+		if (skip >= len) {
+			skip -= len;
+			continue;
+		}
+		line += skip;
+		len -= skip;
+		skip = 0;
+		if (len > n) {
+			len = n;
+		}
+		memcpy(dst, line, (size_t)len);
+		dst += len;
+		n -= len;
+	}
+}
+
 } // namespace nte_host

@@ -6,16 +6,20 @@ The multi-GPU driver of the hot path: one process per GPU, launched with
         -m ntedit_amd.run -f draft.fa -r solid.bf -b out
 
 (or plainly, without a launcher, on one GPU).  Rank 0 reads the Bloom filter file(s) once and ships the bit
-arrays to every GPU with ONE RCCL broadcast each (dist.load_and_broadcast_filter); every rank reads the draft,
-computes the same partition of the contigs by bases -- contigs larger than a GPU's share are cut at event-free
-boundaries (dist.plan_pieces) -- polishes its pieces through the C ABI (ntedit_amd.Polisher = libntedit_hip.so) and
-writes <prefix>.shard<r>_*; rank 0 gathers them into <prefix>_edited.fa / _changes.tsv / _variants.vcf in input
-order.  The output is byte-identical to the single-GPU `ntedit` binary's (and to the reference at -t 1).
+arrays to every GPU with ONE RCCL broadcast each (dist.load_and_broadcast_filter); every rank maps the draft and
+reads its INDEX (headers, lengths: Draft / ntedit_hip_fasta_open), computes the same partition of the contigs by bases --
+contigs larger than a GPU's share are cut at event-free boundaries (dist.plan_pieces) --, reads the bases of ITS pieces
+straight into its page-locked batch, polishes them through the C ABI (ntedit_amd.Polisher = libntedit_hip.so), writes
+<prefix>.shard<r>_*, and -- after the per-piece byte counts have been all-gathered, a few KB -- copies its pieces to
+their offsets in <prefix>_edited.fa / _changes.tsv / _variants.vcf itself (dist.gather_parallel): no rank holds the
+draft, no rank reads another rank's output.  Byte-identical to the single-GPU `ntedit` binary's output (and to the
+reference at -t 1).
 
 What the reference does instead: readAndCorrect's OpenMP loop (ntedit.cpp:2213-2252), contigs handed to threads one
 at a time, output in completion order."""
 import argparse
 import ctypes
+import json
 import os
 import sys
 import time
@@ -53,6 +57,90 @@ def read_fasta_fast(path, min_len=0, threads=0):
         lib.ntedit_hip_fasta_free(h)
 
 
+class LazySlice:
+    """bases [start, end) of a record of a Draft: read when somebody needs them (straight into a page-locked batch
+    buffer with read_into(), or as bytes)"""
+    __slots__ = ("draft", "rec", "start", "end")
+
+    def __init__(self, draft, rec, start, end):
+        self.draft, self.rec, self.start, self.end = draft, rec, int(start), int(end)
+
+    def __len__(self):
+        return self.end - self.start
+
+    def read_into(self, address):
+        self.draft.read_into(self.rec, self.start, self.end, address)
+
+    def __bytes__(self):
+        return self.draft.read(self.rec, self.start, self.end)
+
+
+class LazySeq:
+    """one record's sequence, sliceable: seq[a:b] reads those bases (the 64 KB windows cuts are looked for in),
+    seq.lazy(a, b) only describes them"""
+    __slots__ = ("draft", "rec", "n")
+
+    def __init__(self, draft, rec, n):
+        self.draft, self.rec, self.n = draft, rec, int(n)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, key):
+        if not isinstance(key, slice):
+            raise TypeError("LazySeq takes slices")
+        a, b, step = key.indices(self.n)
+        if step != 1:
+            raise ValueError("LazySeq slices are contiguous")
+        return self.draft.read(self.rec, a, max(a, b))
+
+    def lazy(self, a, b):
+        return LazySlice(self.draft, self.rec, a, b)
+
+
+class Draft:
+    """The draft as a multi-GPU rank needs it: the INDEX of the file -- headers and lengths, found by
+    the library's mapped multi-threaded reader, ntedit_hip_fasta_open -- and its bases on demand.  Every rank plans the same
+    partition from the lengths and then reads ITS OWN pieces (and the windows of its cuts) out of the mapped file;
+    nobody holds the draft.  records() is the [(header, sequence)] list dist.run_sharded takes, with LazySeq
+    sequences.  Inputs the mapped reader does not take (single-stream gzip, FASTQ, ...) are loaded whole by the
+    library; nothing changes for the caller."""
+
+    def __init__(self, path, min_len=0, threads=0):
+        from . import _lib
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        rc = self._lib.ntedit_hip_fasta_open(os.fsencode(path), int(min_len), int(threads), ctypes.byref(self._h), err, len(err))
+        if rc != 0:
+            raise _lib.NtEditHipError("%s (%d)" % (err.value.decode(errors="replace") or "cannot read the draft", rc))
+        self.headers, self.lens = [], []
+        hp, hl, off, ln = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        for i in range(self._lib.ntedit_hip_fasta_count(self._h)):
+            self._lib.ntedit_hip_fasta_record(self._h, i, ctypes.byref(hp), ctypes.byref(hl), ctypes.byref(off), ctypes.byref(ln))
+            self.headers.append(ctypes.string_at(hp.value, hl.value) if hl.value else b"")
+            self.lens.append(int(ln.value))
+        self.bytes_read = 0
+
+    def records(self):
+        return [(h, LazySeq(self, i, n)) for i, (h, n) in enumerate(zip(self.headers, self.lens))]
+
+    def read_into(self, rec, start, end, address):
+        if self._lib.ntedit_hip_fasta_read(self._h, rec, int(start), int(end - start), ctypes.c_void_p(address)) != 0:
+            raise ValueError("draft record %d: bases [%d, %d) are out of range" % (rec, start, end))
+        self.bytes_read += end - start
+
+    def read(self, rec, start, end):
+        buf = ctypes.create_string_buffer(max(1, end - start))
+        self.read_into(rec, start, end, ctypes.addressof(buf))
+        return buf.raw[:end - start]
+
+    def close(self):
+        if self._h:
+            self._lib.ntedit_hip_fasta_free(self._h)
+            self._h = ctypes.c_void_p()
+
+
 class HipBackend:
     """dist.run_sharded's compute backend on the real thing: the HIP library through the C ABI"""
 
@@ -84,7 +172,10 @@ class HipBackend:
         offs, lens, pos = [], [], 0
         for _, seq, _ in entries:
             n = len(seq)
-            buf[pos:pos + n] = np.frombuffer(seq, dtype=np.uint8)
+            if hasattr(seq, "read_into"):
+                seq.read_into(self._pin_ptr + pos)  # (a piece of a Draft: mapped file -> page-locked batch, one copy)
+            else:
+                ctypes.memmove(self._pin_ptr + pos, seq, n)
             buf[pos + n] = 10
             offs.append(pos)
             lens.append(n)
@@ -102,7 +193,7 @@ class HipBackend:
         if pinned is not None:
             blob, offs, lens = pinned
         else:
-            blob, offs, lens, _ = pack_batch([(e[0], e[1]) for e in entries], 0)
+            blob, offs, lens, _ = pack_batch([(e[0], bytes(e[1])) for e in entries], 0)
         res = self.pol.polish_batch(blob, offs, lens)
         # the renderer's own predicate, asked before anything is written (a refused entry would leave the shard
         # files half-written): a cut that is not event-free is polished again joined with its successor
@@ -162,6 +253,10 @@ def main(argv=None):
     if not torch.cuda.is_available():
         sys.stderr.write("ntEdit v2.1.1: error: no HIP device (this build has no CPU path)\n")
         return 1
+    if (args.backend or "nccl") != "nccl":
+        # (rehearsal: `--backend gloo` lets N ranks share the GPUs that are there -- RCCL refuses two ranks on one device --
+        # so the N > 1 path of this driver can be run on a one-GPU box; its timings then say nothing about N GPUs)
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         ndist.init_process_group(args.backend or "nccl")
@@ -206,8 +301,10 @@ def main(argv=None):
             sys.stderr.write("Unable to open file\n")
             annot = ctypes.c_void_p()
 
+    # the draft's index (headers, lengths); a rank reads the bases of its own pieces only (Draft)
     t0 = time.perf_counter()
-    records = read_fasta_fast(args.draft)
+    draft = Draft(args.draft)
+    records = draft.records()
     t_read = time.perf_counter() - t0
 
     # start-up, like the filter load: this rank's buffers for its share of the draft + one internal warm-up batch, so that
@@ -225,22 +322,30 @@ def main(argv=None):
     backend = HipBackend(pol, annot if annot.value else None)
     halo = ndist.halo_bases(k, 0 if p.snv else p.max_insertions, 0 if p.snv else p.max_deletions)
     barrier = dist.barrier if (dist.is_initialized() and world > 1) else None
+
+    def all_gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
     t0 = time.perf_counter()
     mine = ndist.run_sharded(records, backend, prefix, p.min_contig_len, rank, world, k, halo, write_headers,
-                             barrier=barrier, seg_bases=args.seg_bases)
+                             barrier=barrier, seg_bases=args.seg_bases,
+                             all_gather=all_gather if barrier else None)
     if barrier:
         barrier()
     t_run = time.perf_counter() - t0
     if args.report:
         n_seg = sum(1 for q in mine if q.n_seg > 1)
         sys.stdout.write('{"rank": %d, "world": %d, "pieces": %d, "segments": %d, "bases": %d, "reruns": %d, '
-                         '"gpu_ms": %.3f, "filter_s": %.3f, "read_s": %.3f, "reserve_s": %.3f, "run_s": %.3f}\n' %
+                         '"gpu_ms": %.3f, "filter_s": %.3f, "index_s": %.3f, "draft_bases_total": %d, "draft_bytes_read": %d, '
+                         '"reserve_s": %.3f, "run_s": %.3f, "phases_s": %s}\n' %
                          (rank, world, len(mine), n_seg, backend.bases, backend.n_rerun, backend.ms_gpu, t_filter,
-                          t_read, t_reserve, t_run))
+                          t_read, total, draft.bytes_read, t_reserve, t_run, json.dumps(ndist.LAST_PHASES)))
         sys.stdout.flush()
     if annot.value:
         pol._lib.ntedit_hip_annot_free(annot)
     backend.close()
+    draft.close()
     pol.close()
     if dist.is_initialized():
         dist.destroy_process_group()

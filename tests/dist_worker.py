@@ -42,7 +42,7 @@ class HostsimBackend:
         hp = H.default_params(**{f[0]: getattr(self.hp, f[0]) for f in self.hp._fields_})
         hp.min_contig_len = 0
         if prefix is None:
-            blob, offs, lens, names = H.pack_batch([(e[0], e[1]) for e in entries], 0)
+            blob, offs, lens, names = H.pack_batch([(e[0], bytes(e[1])) for e in entries], 0)
             n = len(names)
             rc = lib.hostsim_polish(
                 ctypes.c_char_p(blob), ctypes.c_uint64(len(blob)), offs.ctypes.data_as(ctypes.c_void_p),
@@ -51,7 +51,7 @@ class HostsimBackend:
                 ctypes.c_uint32(self.bf["hash_num"]), ctypes.c_uint32(self.bf["k"]), None, ctypes.c_uint64(0),
                 ctypes.c_uint32(0), ctypes.byref(hp), None, None, None, None, ctypes.c_int(0), ctypes.c_int(0), None, None)
             return rc
-        rc, _, _ = H.run_hostsim([(e[0], e[1]) for e in entries], self.bf, hp, prefix)
+        rc, _, _ = H.run_hostsim([(e[0], bytes(e[1])) for e in entries], self.bf, hp, prefix)
         return rc
 
     def polish(self, entries, fa, tsv, vcf, append):
@@ -106,7 +106,15 @@ def main():
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     assert int(lo) == int(hi) == int(chk)
 
-    recs = H.read_fasta(draft)
+    # DIST_LAZY=1: the draft as the real driver takes it -- index only, bases read on demand (ntedit_amd.run.Draft over
+    # ntedit_hip_fasta_open / _read); else the whole draft in memory
+    lazy = None
+    if os.environ.get("DIST_LAZY") == "1":
+        from ntedit_amd.run import Draft
+        lazy = Draft(draft)
+        recs = lazy.records()
+    else:
+        recs = H.read_fasta(draft)
     hp = H.default_params()
     backend = HostsimBackend(bf, hp, blind)
 
@@ -119,8 +127,18 @@ def main():
         open(pre + "_variants.vcf", "wb").close()
 
     halo = ndist.halo_bases(k, hp.max_insertions, hp.max_deletions)
+    def all_gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+    # DIST_GATHER=parallel: every rank copies its pieces to their places in the final files; else rank 0 merges
     mine = ndist.run_sharded(recs, backend, out_prefix, hp.min_contig_len, rank, world, k, halo, write_headers,
-                             barrier=dist.barrier, seg_bases=seg_bases)
+                             barrier=dist.barrier, seg_bases=seg_bases,
+                             all_gather=all_gather if os.environ.get("DIST_GATHER") == "parallel" else None)
+    if lazy is not None:
+        with open("%s.read%d" % (out_prefix, rank), "w") as f:
+            f.write("%d %d\n" % (lazy.bytes_read, sum(lazy.lens)))
+        lazy.close()
     stats = torch.tensor([len(mine), sum(1 for p in mine if p.n_seg > 1), backend.reruns,
                           sum(p.end - p.start for p in mine)], dtype=torch.int64)
     allst = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]

@@ -33,6 +33,8 @@ extern "C" {
 #define NTEDIT_E_IO (-5)       /* file could not be read / written         */
 #define NTEDIT_E_UNSUPPORTED (-6) /* operation not available (e.g. GPU build of a counting filter) */
 #define NTEDIT_E_SEGMENT (-7)  /* a contig segment's cut is not event-free (see ntedit_hip_segment)      */
+#define NTEDIT_E_INTERNAL (-8) /* an invariant of the library does not hold (the renderer: an event reached across the margin a
+                                  contig's parts are cut with); the output files are incomplete -- a bug to report, not an I/O error */
 
 #define NTEDIT_FILTER_PRIMARY 0   /* -r  (ntedit.cpp:2438) */
 #define NTEDIT_FILTER_SECONDARY 1 /* -e  (ntedit.cpp:2570) */
@@ -167,7 +169,11 @@ int ntedit_hip_bind_near_device(int device);
  * NTEDIT_HIP_BASES_*), and runs one small internal batch through the current configuration so that kernel code,
  * kernel attributes and scratch memory are in place.  Fresh device memory maps at ~40 GB/s (the 84 GB of screening
  * records of a 3 Gbp batch: two seconds); without this call the first ntedit_hip_polish_batch pays that, with it the
- * first call costs what a warm one does.  Never changes a result; may be called again when the configuration changes. */
+ * first call costs what a warm one does.  Never changes a result; may be called again when the configuration changes.
+ * WHAT IT COSTS NOT TO CALL IT (measured, one MI355X): a context's first 3 Gbp batch takes ~2 s more (the record buffers
+ * being mapped) and even with buffers already there its event machine runs 54-57 ms instead of 32 (kernel code objects,
+ * scratch memory and workspaces set up inside the call: `[configs3]` against `[nonpow2]` in profiles/r6_gpu_tests*.log);
+ * a 250 Mbp batch 22.9 ms instead of 13.4.  A caller that binds this ABI and times its first batch should call it. */
 int ntedit_hip_reserve(ntedit_hip_ctx* ctx, uint64_t max_batch_bytes, uint32_t max_contigs, uint64_t events_hint, int on_device);
 
 /* step 1 only (ntedit.cpp:1798-1807): bit i of bitmap (ceil(n/64) words,

@@ -20,6 +20,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <sys/stat.h>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
@@ -435,7 +436,25 @@ main(int argc, char** argv)
 	// measured page-locking as a loss because it paid for it inside the timed region, three buffers of 1 GiB.
 	Work pool[3];
 	const unsigned long long batch_cap_bases = batch_given ? batch_bases : (1ull << 30);
-	const size_t pin_bytes = (size_t)(batch_cap_bases < (1ull << 32) ? batch_cap_bases : (1ull << 32)) + (size_t)(64u << 20);
+	size_t pin_bytes = (size_t)(batch_cap_bases < (1ull << 32) ? batch_cap_bases : (1ull << 32)) + (size_t)(64u << 20);
+	{
+		//  a small draft does not pay for the largest batch: a plain FASTA file holds no more bases than it has
+		// bytes (3 x 1 GiB of page-locked memory and ~30 GB of device buffers for a 5 Mbp draft otherwise).  Compressed
+		// drafts keep the full size: their length is not known in advance.
+		struct stat sb;
+		FILE* probe = fopen(draft.c_str(), "rb");
+		if (probe) {
+			unsigned char magic[2] = { 0, 0 };
+			const bool gz = fread(magic, 1, 2, probe) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+			if (!gz && fstat(fileno(probe), &sb) == 0 && S_ISREG(sb.st_mode)) {
+				const size_t by_file = (size_t)sb.st_size + (size_t)(4u << 20);
+				if (by_file < pin_bytes) {
+					pin_bytes = by_file;
+				}
+			}
+			fclose(probe);
+		}
+	}
 	std::thread pin_thread([&]() {
 		(void)ntedit_hip_bind_near_device(gpu);
 		if (no_map || getenv("NTEDIT_NO_PINNED_BATCHES")) {
@@ -521,8 +540,8 @@ main(int argc, char** argv)
 	// start-up, like the filter load: the context's buffers for the largest batch + one internal warm-up batch, so that
 	// the first polish_batch call costs what the later ones do (ntedit_hip_reserve)
 	if (ntedit_hip_reserve(ctx, pin_bytes, 1u << 16, 0, no_pack ? NTEDIT_HIP_BASES_HOST : NTEDIT_HIP_BASES_PACKED) != 0) {
-		fprintf(stderr, PROGRAM ": error: %s\n", ntedit_hip_last_error(ctx));
-		fatal();
+		// (optional: the buffers then grow on demand, inside the first calls)
+		fprintf(stderr, PROGRAM ": warning: buffers could not be sized ahead (%s); they grow on demand\n", ntedit_hip_last_error(ctx));
 	}
 	pin_thread.join();
 

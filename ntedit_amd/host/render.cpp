@@ -739,18 +739,24 @@ render_contig(const BatchView& v, uint32_t ci, size_t ev, size_t ev_end, ContigO
 class FlatPool
 {
   public:
+	// best fit (first fit handed a 300 MB buffer to a 1 MB unit while the next large unit allocated another)
 	char* take(size_t bytes, size_t* cap)
 	{
 		{
 			std::lock_guard<std::mutex> lk(mu_);
+			size_t best = bufs_.size();
 			for (size_t i = 0; i < bufs_.size(); i++) {
-				if (bufs_[i].second >= bytes) {
-					char* p = bufs_[i].first;
-					*cap = bufs_[i].second;
-					bufs_[i] = bufs_.back();
-					bufs_.pop_back();
-					return p;
+				if (bufs_[i].second >= bytes && (best == bufs_.size() || bufs_[i].second < bufs_[best].second)) {
+					best = i;
 				}
+			}
+			if (best < bufs_.size()) {
+				char* p = bufs_[best].first;
+				*cap = bufs_[best].second;
+				held_ -= bufs_[best].second;
+				bufs_[best] = bufs_.back();
+				bufs_.pop_back();
+				return p;
 			}
 		}
 		const size_t want = bytes + bytes / 4 + (1u << 20);
@@ -758,14 +764,16 @@ class FlatPool
 		*cap = p ? want : 0;
 		return p;
 	}
+	// kept for the next unit while the pool holds fewer than 96 buffers and less than 2 GiB; the rest goes back to the system
 	void give(char* p, size_t cap)
 	{
 		if (!p) {
 			return;
 		}
 		std::lock_guard<std::mutex> lk(mu_);
-		if (bufs_.size() < 96) {
+		if (bufs_.size() < 96 && held_ + cap <= (size_t(2) << 30)) {
 			bufs_.emplace_back(p, cap);
+			held_ += cap;
 		} else {
 			free(p);
 		}
@@ -774,6 +782,7 @@ class FlatPool
   private:
 	std::mutex mu_;
 	std::vector<std::pair<char*, size_t>> bufs_;
+	size_t held_ = 0;
 };
 FlatPool g_flat_pool;
 
@@ -1233,11 +1242,21 @@ render_batch(
 		if (P == 1) {
 			scan(0);
 		} else {
+			// (a thread that cannot be started -- std::system_error must not cross the C ABI with joinable threads behind
+			// it -- leaves its range to this one)
 			std::vector<std::thread> th;
+			std::vector<unsigned> left;
 			for (unsigned t = 1; t < P; t++) {
-				th.emplace_back(scan, t);
+				try {
+					th.emplace_back(scan, t);
+				} catch (...) {
+					left.push_back(t);
+				}
 			}
 			scan(0);
+			for (unsigned t : left) {
+				scan(t);
+			}
 			for (std::thread& t : th) {
 				t.join();
 			}

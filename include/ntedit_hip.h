@@ -398,7 +398,10 @@ void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
  *               overflow list), "bin_ovf_cap" (entries of the overflow list: forces a list that runs out, i.e. record chunks
  *               screened again by the direct kernel), "bin_fallback" (1: the direct kernel, like "screen_mode" 1), "bin_scatter"
  *               (1: the barrier-free partition kernel, kept as the second implementation the tests compare),
- *               "force_xcc" (x + 1: the probe stage behaves as if every wavefront ran on XCD x), "bin_timing"
+ *               "force_xcc" (x + 1: the probe stage behaves as if every wavefront ran on XCD x), "bin_timing",
+ *               "candmap" (1: with -s 1 on a plain filter the first probes of every position's substitution candidates go
+ *               through the partitioned pipeline before k_assess; exact, measured slower, off), "h2d_fixed_schedule" (1: a
+ *               host batch is screened in round 3's fixed chunk schedule instead of chunks sized by arrival)
  *   batches     "chunk_bytes" (pipeline chunk size), "h2d_piece" (bytes per host-to-device piece)
  *   machine     "inline_tries", "no_rounds", "force_rounds", "no_early_copy", "lanes" (runs of failing positions one
  *               position per lane: 0 off, 1 in the clean state, 2 also behind substitutions), "defer_fail" (failing positions after which the thread-per-event launch hands an event

@@ -92,6 +92,7 @@ struct ntedit_hip_ctx
 	hipEvent_t ev_assess[2] = { nullptr, nullptr };
 	DevBuf packed; // a batch as it crossed PCIe in the packed form (NTEDIT_HIP_BASES_PACKED), before k_unpack
 	DevBuf runmap; // the absent bitmap minus the positions that cannot do anything (k_assess)
+	DevBuf candmap; // -s 1 on a plain filter: 4 bits per position, the first-probe bits of its substitution candidates (k_wc_scatter_b<3, ., 1>)
 	DevBuf seq, bitmap, block_counts, block_offsets, events, first_chunk, arena, counters, deferred;
 	DevBuf ws_nodes, ws_ov_pos, ws_ov_chr, ws_prev, ws_lps, ws_win;
 	DevBuf offs, lens;
@@ -100,6 +101,7 @@ struct ntedit_hip_ctx
 	{
 		u64 begin, end;  // k-mer starts of one record chunk
 		bool recovered;  // its overflow list ran out and the direct kernel has screened it again
+		bool gate;       // a chunk of the candidate map (-s 1): "screened again" = its part of the map set to unknown
 	};
 	std::vector<BinRange> bin_ranges; // the record chunks of the current call, in launch order (bin_state's flags)
 	std::vector<u32> bin_flags_host;
@@ -123,7 +125,9 @@ struct ntedit_hip_ctx
 		u32 lanes = ~0u;         // DevParams::lanes (~0: default)
 		u32 defer_run = ~0u;     // DevParams::defer_run (~0: default)
 		u32 defer_fail = ~0u;    // DevParams::defer_fail (~0: default)
+		u32 defer_fail_snv = ~0u; // DevParams::defer_fail_snv (~0: default)
 		u32 h2d_fixed_schedule = 0; // a batch arriving in pieces: round 3's chunk schedule (1, 3, 8 pieces, the rest) instead of chunks by arrival
+		u32 candmap = 0;         // the candidate map of -s 1 (nte_bin_wc.inc MODE 1): 1 = whenever the configuration allows it (measured slower: off)
 		u32 snv_wave = 0;        // -s 1 with the run map: the events go to the wavefront-per-event launch (experiment)
 		u32 no_rounds = 0, no_early_copy = 0;
 		u32 force_rounds = 0;     // event rounds whatever the number of events (tests: small inputs)
@@ -314,6 +318,9 @@ refresh_params(ntedit_hip_ctx* c)
 	}
 	if (c->tune.defer_fail != ~0u) {
 		c->dp.defer_fail = c->tune.defer_fail;
+	}
+	if (c->tune.defer_fail_snv != ~0u) {
+		c->dp.defer_fail_snv = c->tune.defer_fail_snv;
 	}
 	if (!c->d_tab) {
 		HIP_TRY(c, hipMalloc((void**)&c->d_tab, TAB_WORDS * sizeof(u64)));

@@ -36,6 +36,9 @@ k_assess(AssessArgs a)
 {
 	__shared__ __attribute__((aligned(16))) u64 s_tab[TAB_WORDS];
 	__shared__ __attribute__((aligned(16))) u8 s_win[ASSESS_MAX_WIN];
+	__shared__ u32 s_list[ASSESS_TILE]; // second phase: (window offset << 4) | candidates there
+	__shared__ u32 s_keep[ASSESS_TPB];  // the lanes' keep bits, completed by the second phase
+	__shared__ u32 s_n_list;
 	if (threadIdx.x < TAB_WORDS) {
 		s_tab[threadIdx.x] = a.tabs[threadIdx.x];
 	}
@@ -69,6 +72,9 @@ k_assess(AssessArgs a)
 	env.defer_sweeps = false;
 	env.wave_size = 1;
 	const u32 x0 = threadIdx.x * ASSESS_L;
+	if (threadIdx.x == 0) {
+		s_n_list = 0;
+	}
 	for (u64 tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
 		const u64 base = a.pos_begin + tile * ASSESS_TILE; // (a multiple of 64)
 		__syncthreads(); // (the window of the previous tile is no longer read)
@@ -101,6 +107,12 @@ k_assess(AssessArgs a)
 		// (a byte the 4-bit codes cannot express anywhere in the tile: every absent position keeps its bit)
 		const bool plain = !__syncthreads_or(exotic ? 1 : 0);
 		u32 keep = abits;
+		// (the candidate map applies where the gate's first question comes first: not with -m 2 / -a, plain filters only)
+		const bool use_cmap = a.cand_map != nullptr && a.p.mode != 2 && !a.p.mask && !a.p.counting;
+		u64 cmap = 0;
+		if (use_cmap && abits) {
+			cmap = *reinterpret_cast<const u64*>(a.cand_map + (p0 >> 3)); // 16 positions x 4 bits (p0 is a multiple of 16)
+		}
 		if (plain && abits) {
 			MachineT<0> m(env); // (the general machine: an instantiation for -m 0 / no secondary filter / power-of-two sizes
 			                    // was built in round 5 and ran SLOWER, 40.5 against 35.7 ms per 250 Mbp with -s 1)
@@ -113,16 +125,39 @@ k_assess(AssessArgs a)
 				good = s_win[x0 + i] != CODE_BAD ? good + 1 : 0;
 			}
 			keep = 0;
+			// Two phases (round 6).  One position in 27 gets past the gate's first question, but of the 64 positions a
+			// wavefront assesses together nearly always one does -- and the others wait while it runs step 2 and its
+			// candidates' support walks, twenty dependent probe rounds, on ONE lane: 32 of the kernel's 36 ms per 250 Mbp
+			// with -s 1.  So the lanes ask the first question only, as they roll along their positions, and put the
+			// positions that pass on a list in the LDS; the rest of the assessment then runs on that list, every lane a
+			// survivor.  (-m 2 / -a: the first question is not the first, assess_gate as before.)
+			const bool two_phase = a.p.mode != 2 && !a.p.mask;
 			for (u32 j = 0; j < (u32)ASSESS_L; j++) {
 				if ((abits >> j) & 1) {
 					bool kp = true;
 					m.win_off = x0 + j;
-					if (good >= need) {
+					if (use_cmap) {
+						// the candidate map: which of the position's candidates have the first bit of their k-mer set.  None:
+						// no candidate's k-mer is there, the position is a no-op -- without a single gather.
+						m.cand_l1 = (u32)((cmap >> (4 * j)) & 15u);
+					}
+					if (use_cmap && m.cand_l1 == 0) {
+						kp = false;
+					} else if (two_phase) {
+						m.hs = hs;
+						const u32 there = m.gate_candidates();
+						kp = there != 0;
+						if (kp && good >= need) {
+							// (a position without a full window -- a contig ends, a non-accepted character is ahead -- keeps
+							// its bit on the first question alone; the others go on the list)
+							kp = false;
+							const u32 at = atomicAdd(&s_n_list, 1u);
+							s_list[at] = ((x0 + j) << 4) | there;
+						}
+					} else if (good >= need) {
 						m.hs = hs;
 						kp = m.assess_gate(p0 + j, a.seq[p0 + j + k - 1]);
 					} else {
-						// no full window (a contig ends, a non-accepted character is ahead): the k-mer's own codes -- accepted,
-						// or the bit would not be set -- answer the gate's first question
 						m.hs = m.seed_from_window();
 						kp = m.assess_gate_kmer_only();
 					}
@@ -139,6 +174,31 @@ k_assess(AssessArgs a)
 			// 35.9 ms; 6 / 8 waves per SIMD (80 / 64 registers) 41.1 / 43.5 ms; an instantiation of the machine for the
 			// configuration 40.5 ms.  The kernel's TCPs wait for misses 87 % of the time at 29 G fabric requests/s
 			// (profiles/r5_assess_counters.txt): what it lacks is not requests in flight.)
+		}
+		// ---- second phase: the listed positions, one per lane
+		if (plain) {
+			s_keep[threadIdx.x] = keep;
+		}
+		__syncthreads();
+		if (plain) {
+			const u32 n_list = s_n_list;
+			for (u32 q = threadIdx.x; q < n_list; q += ASSESS_TPB) {
+				const u32 ent = s_list[q];
+				const u32 x = ent >> 4;
+				MachineT<0> m(env);
+				m.win_ok = true;
+				m.win_off = x;
+				m.hs = m.seed_from_window();
+				m.there_known = ent & 15u;
+				if (m.assess_gate(base + x, a.seq[base + x + k - 1])) {
+					atomicOr(&s_keep[x / ASSESS_L], 1u << (x % ASSESS_L));
+				}
+			}
+			__syncthreads();
+			keep = s_keep[threadIdx.x];
+			if (threadIdx.x == 0) {
+				s_n_list = 0;
+			}
 		}
 		// four lanes = one word
 		const u32 k1 = (u32)__shfl_down((int)keep, 1, 64), k2 = (u32)__shfl_down((int)keep, 2, 64), k3 = (u32)__shfl_down((int)keep, 3, 64);

@@ -362,6 +362,7 @@ struct DevParams
 	                   // goes on for at least this many positions is handed to the wavefront-per-event launch (0 = never)
 	u32 defer_fail;    // thread-per-event launch: an event that has gone through this many failing positions (a chain of
 	                   // edits in repetitive sequence: one lane at work, 63 waiting for it) goes there as well (0 = never)
+	u32 defer_fail_snv; // the same with -s 1, where every position an event goes through counts (0 = never)
 	u64 mul[MAX_HASHES]; // mul[i] = i ^ (k * MULTISEED), i >= 1
 };
 

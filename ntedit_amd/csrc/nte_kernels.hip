@@ -346,6 +346,7 @@ struct ProbeArgs
 	u32 counting;    // the filter holds 8-bit counters: a slot is a byte, "absent" = counter < count_lo
 	u32 count_lo;    // max(1, -p) (ntedit.cpp:1806)
 	u32 plog;        // log2 of the parts a slice is probed in (0: whole slices)
+	u32 mark_present; // 1: OR the bit of a record whose slot IS set (the candidate map of -s 1) instead of the absent ones
 };
 
 __device__ __forceinline__ u32
@@ -484,7 +485,7 @@ k_bin_probe(ProbeArgs a)
 			const u32 off = (u32)(rec[q] & off_mask);
 			// plain filter: the bit; counting filter: the counter must reach max(1, -p)
 			const bool absent = a.counting ? (u32)byte[q] < a.count_lo : !((byte[q] >> (off & 7)) & 1);
-			if (absent && rec[q] != WC_EMPTY_REC) {
+			if (absent != (a.mark_present != 0) && rec[q] != WC_EMPTY_REC && (off >> part_shift) == part) {
 				const u64 pos = (rec[q] & WC_REC_POS_MASK) >> a.slog;
 				atomicOr(&a.absent32[pos >> 5], 1u << (pos & 31));
 			}

@@ -245,6 +245,8 @@ struct MachineT
 	bool wc_valid;      // the window holds a clean stretch of draft codes starting at wc_pos0
 	u32 wc_pos0, wc_len;
 	u32 win_off;        // offset of the current failing position inside that stretch
+	u32 cand_l1 = ~0u;  // k_assess with the candidate map of -s 1: first-probe bits of this position's candidates (~0: not known)
+	u32 there_known = ~0u; // k_assess, second phase: the candidates whose own k-mer is there, found by the first phase (~0: ask)
 	// presence of the next k-mers while the window still overlaps an edit (see build_lookahead)
 	u32 la_mask, la_n, la_i;
 	bool la_off;

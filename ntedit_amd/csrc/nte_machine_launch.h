@@ -73,6 +73,7 @@ struct AssessArgs
 	DevParams p;
 	Filter bloom, rep;
 	u64 pos_begin, pos_end, n_tiles;
+	const u32* cand_map; // -s 1, plain filter: 4 bits per position (nte_bin_wc.inc MODE 1), or null
 };
 void launch_k_assess(unsigned blocks, hipStream_t stream, const AssessArgs& a);
 int assess_tile();

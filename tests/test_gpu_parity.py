@@ -794,6 +794,41 @@ def test_errors_in_front_of_contig_ends_gpu(tmp_path, oracle_build, kw):
         assert H.vcf_body(str(tmp_path / "o_variants.vcf")) == H.vcf_body(str(tmp_path / "g_variants.vcf"))
 
 
+@pytest.mark.parametrize("kw", [dict(snv=1), dict(snv=1, max_insertions=0, max_deletions=0), dict(snv=1, mode=1),
+                                dict(snv=1, jump=1), dict(snv=1, k=40)])
+def test_snv_candidate_map(tmp_path, oracle_build, kw):
+    """-s 1 on a plain filter (round 6): the first probes of every position's substitution candidates go through the
+    partitioned pipeline (the candidate map, nte_bin_wc.inc MODE 1) and k_assess probes on from the second hash --
+    forced here on small inputs ("candmap" 1), in several record chunks, with an overflow list that runs out (those
+    chunks' part of the map becomes "unknown") and on a filter whose size is not a power of two: same bytes as the
+    oracle, and as the run without the map"""
+    kw = dict(kw)
+    k = kw.pop("k", 25)
+    for flavor, bfbytes in (("N lower iupac", 1 << 22), ("N rep", 3_000_001)):
+        sub = tmp_path / ("c%d" % bfbytes)
+        case = H.make_case(str(sub), 8100 + k, n=150000, contigs=3, k=k, flavor=flavor, bfbytes=bfbytes)
+        hp = H.default_params(**kw)
+        H.run_oracle(case["draft"], case["bf"], hp, str(sub / "o"))
+        recs = H.read_fasta(case["draft"])
+        for tag, tunes in (("map", dict(candmap=1)), ("chunks", dict(candmap=1, bin_chunk=3 * 16384)),
+                           ("lost", dict(candmap=1, bin_chunk=3 * 16384, bin_cap_percent=5, bin_ovf_cap=4096)),
+                           ("nomap", dict(candmap=0))):
+            pol = _fresh()
+            try:
+                _load_filters(pol, case)
+                pol.set_params(_hip_params(**kw))
+                for key, val in tunes.items():
+                    pol.set_tuning(key, val)
+                st = pol.polish_records(recs, str(sub / tag))
+            finally:
+                pol.close()
+            for suf in ("_changes.tsv", "_edited.fa"):
+                assert filecmp.cmp(str(sub / ("o" + suf)), str(sub / (tag + suf)), shallow=False), (tag, suf)
+            assert H.vcf_body(str(sub / "o_variants.vcf")) == H.vcf_body(str(sub / (tag + "_variants.vcf"))), tag
+            if tag == "lost":
+                assert st.screen_chunks_direct > 0
+
+
 def test_parked_events_resolve_quickly(tmp_path, oracle_build):
     """Nearly every event parked by a tiny budget on a draft where hardly a k-mer is in the filter (the regime of fuzz seed
     42424200091: k=128, 1.7 % errors, budget 8; a third of its length here).  What the serial order applies there is ONE

@@ -4,7 +4,7 @@
 TAG=${1:-final}; FZ=${2:-4}
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-timeout 1200 python -m pytest tests -q -m gpu -x -s 2>&1 | grep -v "amdgpu.ids" > $OUT/gpu_tests.log; tail -2 $OUT/gpu_tests.log
+timeout 2400 python -m pytest tests -q -m gpu -x -s 2>&1 | grep -v "amdgpu.ids" > $OUT/gpu_tests.log; tail -2 $OUT/gpu_tests.log
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-600 $OUT/bench.json
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace -o trace -- \
    python $GRAFT_REPO_ROOT/bench.py --bases 3e9 --steps 2 --warmup 1 --no-cpu-baseline --no-gather --no-regions --no-reserve > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/trace.err)

@@ -685,7 +685,7 @@ hostsim_tables_dump(char* out, size_t cap)
 			return -1;
 		}
 	}
-	put("\n");
+	put("%c", (int)10);
 	for (int snv = 0; snv < 2; snv++) {
 		for (const char* c = "ATCGRYSWKMBDHVN"; *c; c++) {
 			u8 cand[8];
@@ -696,7 +696,7 @@ hostsim_tables_dump(char* out, size_t cap)
 			for (u32 q = 0; q < nc; q++) {
 				put("%c", cand[q]);
 			}
-			put("\n");
+			put("%c", (int)10);
 		}
 	}
 	for (const char* c = "ACGT"; *c; c++) {
@@ -711,7 +711,7 @@ hostsim_tables_dump(char* out, size_t cap)
 				return -1;
 			}
 		}
-		put("\n");
+		put("%c", (int)10);
 	}
 	return (long)n;
 }

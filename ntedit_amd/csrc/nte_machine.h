@@ -142,6 +142,33 @@ bit_absent(const u64* bitmap, u64 g)
 	return (bitmap[g >> 6] >> (g & 63)) & 1;
 }
 
+// absent bits among positions g, g + jump, g + 2 jump, ... below g + k (step 2 in the clean state reads the screening's
+// answers, ntedit.cpp:1826-1858): the words that hold them are loaded first, all at once, and the bits are counted from
+// registers -- k / jump loads of single bits, one after the other in a loop of unknown length, were nine round trips to
+// the L2 at k = 25 (round 6).  k <= 200: at most five words.
+NTE_HD u32
+absent_count_stride(const u64* bitmap, u64 g, u32 k, u32 jump)
+{
+	const u64 w0 = g >> 6;
+	const u32 gb = (u32)(g & 63);
+	const u32 nw = (gb + k + 63) >> 6;
+	u64 w[5];
+	NTE_UNROLL
+	for (int i = 0; i < 5; i++) {
+		w[i] = (u32)i < nw ? bitmap[w0 + i] : 0;
+	}
+	u32 n = 0, q = 0;
+	NTE_UNROLL
+	for (int i = 0; i < 5; i++) {
+		const u32 lim = 64u * (u32)(i + 1) - gb; // positions q < lim lie in word i
+		while (q < k && q < lim) {
+			n += (u32)((w[i] >> ((gb + q) & 63)) & 1);
+			q += jump;
+		}
+	}
+	return n;
+}
+
 // event-start predicate shared by the extraction kernel and the machine
 NTE_HD bool
 is_event_start(const u64* bitmap, u64 g, u32 grid)

@@ -405,7 +405,8 @@ void ntedit_hip_fasta_free(ntedit_hip_fasta* f);
  *   batches     "chunk_bytes" (pipeline chunk size), "h2d_piece" (bytes per host-to-device piece)
  *   machine     "inline_tries", "no_rounds", "force_rounds", "no_early_copy", "lanes" (runs of failing positions one
  *               position per lane: 0 off, 1 in the clean state, 2 also behind substitutions), "defer_fail" (failing positions after which the thread-per-event launch hands an event
- *               over), "defer_run" (hand-over
+ *               over; "defer_fail_snv": the same with -s 1, measured slower, 0), "snv_wave" (1: the events of -s 1 go to the
+ *               wavefront-per-event launch; measured slower), "defer_run" (hand-over
  *               threshold of the thread-per-event launch), "assess" (the run map: 0 never, 1 always; default: with -s 1
  *               and counting filters), "machine_cfg" (0: the general instantiation of the machine kernels)
  * (The measured-and-rejected variants of round 3 -- record chunks partitioned while the previous one is probed, slices

@@ -29,7 +29,8 @@ constexpr int ASSESS_MAX_WIN = ASSESS_TILE + 2 * 200 + 10 + 1 + 32; // k <= 200,
 // of a position has to hold k + win_len_in() of them), and asks Machine::assess_gate() where the absent bitmap has the
 // position.  Four lanes make one word of the run map.
 #ifndef NTE_ASSESS_MIN_BLOCKS
-#define NTE_ASSESS_MIN_BLOCKS 4 // blocks of 256 per CU the register allocation leaves room for (118 VGPRs as it falls out)
+#define NTE_ASSESS_MIN_BLOCKS 5 // blocks of 256 per CU the register allocation leaves room for (round 6, the kernel in two phases:
+                                // 4 / 5 / 6 / 7 blocks -> -s 1 19.0 / 18.5 / 19.3 / 19.3 ms, counting filter 30.6 / 28.9 / 28.8 / 28.1)
 #endif
 __global__ __launch_bounds__(ASSESS_TPB, NTE_ASSESS_MIN_BLOCKS) void
 k_assess(AssessArgs a)

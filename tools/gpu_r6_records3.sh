@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 6, the build as shipped (after experiment 58): smoke, the whole GPU tier, the default bench line, machine probe counts,
+# round 6, the build as shipped (after experiment 61: register budgets of the wavefront-per-event kernel and of k_assess): smoke, the whole GPU tier, the default bench line, machine probe counts,
 # kernel-trace stats + PMC passes (stamped with the build id), the side lines
 cd "$GRAFT_REPO_ROOT" || exit 1
-T=r6final3
+T=r6final4
 mkdir -p gpurun_out/$T
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$T/smoke.log 2>&1; tail -1 gpurun_out/$T/smoke.log
 timeout 2400 python -m pytest tests -q -m gpu -x -s 2>&1 | grep -v "amdgpu.ids" > gpurun_out/$T/gpu_tests.log; tail -2 gpurun_out/$T/gpu_tests.log
@@ -16,7 +16,7 @@ for N in 3.0e9 1.0e9; do
   python bench.py --structure genome --bases $N --steps 3 --warmup 1 $B > gpurun_out/$T/bench_genome_$N.json 2> /dev/null
 done
 NTEDIT_HIP_LIB=$PWD/ntedit_amd/libntedit_hip_prof.so NTEDIT_HIP_DEBUG=1 python bench.py --structure genome --steps 1 --warmup 1 $B 2>&1 >/dev/null | grep -E "machine filter" | tail -1 > gpurun_out/$T/genome_machine_probes.txt
-bash tools/profile_gpu.sh r6c > gpurun_out/$T/profile_gpu.log 2>&1
+bash tools/profile_gpu.sh r6d > gpurun_out/$T/profile_gpu.log 2>&1
 for f in bench_snv_250Mbp bench_counting_250Mbp bench_genome_3.0e9 bench_genome_1.0e9; do python -c "
 import json; j=json.load(open('gpurun_out/$T/$f.json')); print('$f', j['ms_per_step'], j['value'], j['phases_ms'])"; done
 cat gpurun_out/$T/genome_machine_probes.txt

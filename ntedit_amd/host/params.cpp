@@ -151,7 +151,7 @@ make_dev_params(
 	d.defer_run = 8; // ... when the clean run goes on for at least 8 more positions (3 Gbp: 2 / 4 / 8 / 16 -> machine 32.4 / 32.7 / 32.0 / 32.7 ms)
 	d.defer_fail = 3; // (round 6; 3 Gbp genome-like draft: 0 / 2 / 3 / 4 / 8 -> machine 98.3 / 80.7 / 80.1 / 82.0 / 83.8 ms; i.i.d. draft 33.9 / 36.7 / 33.0 / 32.9 / 32.8)
 	d.defer_fail_snv = 0;
-	d.inline_tries = 16; // (3 Gbp bench: 4 / 8 / 16 tries -> machine 32.8 / 32.4 / 31.9 ms; round 3, before the lanes: 47.8 / 47.2 / 47.6)
+	d.inline_tries = 8; // (3 Gbp bench, round 6 with the wavefront-per-event kernel at 168 registers: 2 / 4 / 8 / 12 / 16 tries -> machine 33.5 / 31.7 / 30.9 / 31.0 / 31.4 ms, genome-like 72.4 / 71.9 / 72.2 / 73.1 / 74.8; rounds 3-5: 16)
 	for (uint32_t i = 0; i < nte::MAX_HASHES; i++) {
 		d.mul[i] = (uint64_t)i ^ ((uint64_t)k * nte::MULTISEED);
 	}
